@@ -1,0 +1,312 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own classes (build container only).
+
+Run:  python oracle/make_golden.py            (needs /root/reference; CPU only)
+
+The reference's DiffPool classes do not construct as shipped, so
+the import is patched in-process, with no edits to the reference files
+(SURVEY.md Appendix C):
+
+  P1  .cuda() is a no-op (no GPU here; hard-coded .cuda() calls, Appendix B D8)
+  P2  encoders.GraphConv := oracle GraphConv (the DiffPool GraphConv only
+      survives as a comment block, encoders.py:945-974)
+  P3  while SoftPoolingGcnEncoder.loss runs: the 1-element clamp tensor built by
+      torch.Tensor(1) is ones (D5) and `1 - mask.byte()` is a boolean NOT (D6)
+
+Everything else — gcn_forward, apply_bn, construct_mask, forward, loss, Set2Set,
+MeanAggregator — is the reference's code executing.  Fixtures hold inputs,
+parameters by state_dict key, outputs and gradients; never reference source.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("DIFFPOOL_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import diffpool_oracle as O  # noqa: E402
+
+# ---- P1
+torch.Tensor.cuda = lambda self, *a, **k: self
+nn.Module.cuda = lambda self, *a, **k: self
+
+import encoders as R            # noqa: E402  (reference)
+import set2set as RS            # noqa: E402
+import aggregators as RA        # noqa: E402
+
+# ---- P2
+R.GraphConv = O.GraphConv
+
+
+class _NotMask(torch.Tensor):
+    """uint8-mask stand-in whose `1 - m` is the boolean complement (P3 / D6)."""
+
+    @staticmethod
+    def wrap(t):
+        return torch.Tensor._make_subclass(_NotMask, t.to(torch.bool))
+
+    def __rsub__(self, other):
+        return torch.logical_not(self.as_subclass(torch.Tensor))
+
+
+class _LossPatches:
+    """Context manager for P3."""
+
+    def __enter__(self):
+        self._byte = torch.Tensor.byte
+        self._min = torch.min
+        torch.Tensor.byte = lambda t: _NotMask.wrap(t)
+
+        def patched_min(a, b=None, *args, **kw):
+            if isinstance(b, torch.Tensor) and b.numel() == 1 and a.dim() == 3:
+                b = torch.ones(1, dtype=a.dtype)
+            return self._min(a, b, *args, **kw) if b is not None else self._min(a, *args, **kw)
+        torch.min = patched_min
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.byte = self._byte
+        torch.min = self._min
+
+
+def ref_loss(model, ypred, label, adj=None, num_nodes=None):
+    with _LossPatches():
+        return model.loss(ypred, label, adj, num_nodes)
+
+
+def to_np(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **to_np(arrs))
+    print("wrote", path, os.path.getsize(path) // 1024, "KB")
+
+
+def load_params(model, params):
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(params.keys()), (sorted(sd.keys()), sorted(params.keys()))
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(params[k].shape), (k, sd[k].shape, params[k].shape)
+    model.load_state_dict({k: v.clone() for k, v in params.items()})
+
+
+def pack_params(prefix, params):
+    return {f"{prefix}{k}": v for k, v in params.items()}
+
+
+# =========================================================================== G2
+def g2_apply_bn():
+    torch.manual_seed(2)
+    m = R.GcnEncoderGraph(3, 8, 8, 2, 3)
+    x = torch.randn(5, 12, 7)
+    x[:, 9:, :] = 0.25          # node indices whose rows are identical across batch & features -> var = 0
+    x[:, 11, :] = 0.0
+    x.requires_grad_(True)
+    y = m.apply_bn(x)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(3))
+    (y * g).sum().backward()
+    save("g2_apply_bn", x=x, y=y, gy=g, gx=x.grad)
+
+
+# =========================================================================== G3
+def g3_gcn_forward():
+    B, N, F_, H, E = 3, 16, 5, 8, 6
+    x, adj, nn_, _ = O.make_batch(B, N, F_, n_min=1, sizes=[1, 9, 16], p=0.3, seed=5, onehot=False)
+    m = R.GcnEncoderGraph(F_, H, E, 2, 3)
+    params = O.init_params({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=11, bias_scale=0.2)
+    load_params(m, params)
+    mask = m.construct_mask(N, nn_)
+    xg = x.clone().requires_grad_(True)
+    z = m.gcn_forward(xg, adj, m.conv_first, m.conv_block, m.conv_last, mask)
+    g = torch.randn(z.shape, generator=torch.Generator().manual_seed(6))
+    (z * g).sum().backward()
+    grads = {f"grad.{k}": p.grad for k, p in m.named_parameters() if p.grad is not None}
+    save("g3_gcn_forward", x=x, adj=adj, num_nodes=nn_, mask=mask, z=z, gz=g, gx=xg.grad,
+         **pack_params("param.", params), **grads)
+
+
+# ====================================================================== G4 + G5
+def softpool_case(name, *, B, N, F_, H, E, C, ratio, sizes, p, onehot, seed, linkpred, bias_scale):
+    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=1, sizes=sizes, p=p, seed=seed, onehot=onehot,
+                                      n_classes=C)
+    m = R.SoftPoolingGcnEncoder(N, F_, H, E, C, 3, H, assign_ratio=ratio, num_pooling=1,
+                                linkpred=linkpred)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    # cross-check the oracle's own shape table (pins SURVEY.md Appendix D)
+    mine = O.softpool_param_shapes(max_num_nodes=N, input_dim=F_, hidden_dim=H, embedding_dim=E,
+                                   label_dim=C, num_layers=3, assign_hidden_dim=H, assign_ratio=ratio)
+    assert mine == shapes, (mine, shapes)
+    params = O.init_params(shapes, seed=seed + 100, bias_scale=bias_scale)
+    load_params(m, params)
+    m.train()
+    ypred = m(x, adj, nn_, assign_x=x)
+    s = m.assign_tensor
+    s.retain_grad()
+    loss = ref_loss(m, ypred, label, adj, nn_) if linkpred else m.loss(ypred, label)
+    loss.backward()
+    out = dict(x=x, adj=adj, num_nodes=nn_, label=label, ypred=ypred, assign=s, loss=loss,
+               cfg=np.array([B, N, F_, H, E, C, int(N * ratio), int(linkpred)]))
+    if linkpred:
+        out["link_loss"] = m.link_loss
+    # pooled X', A' recomputed from the reference's own S and embedding (forward does not keep them)
+    with torch.no_grad():
+        mask = m.construct_mask(N, nn_)
+        z0 = m.gcn_forward(x, adj, m.conv_first, m.conv_block, m.conv_last, mask)
+        out["z0"] = z0
+        out["xpool"] = torch.matmul(s.transpose(1, 2), z0)
+        out["adjpool"] = s.transpose(1, 2) @ adj @ s
+    grads = {f"grad.{k}": p.grad for k, p in m.named_parameters()}
+    assert all(v is not None for v in grads.values())
+    save(name, **out, **pack_params("param.", params), **grads)
+
+
+def g4_g5_softpool():
+    softpool_case("g4_softpool_n16_f3", B=4, N=16, F_=3, H=8, E=8, C=6, ratio=0.25,
+                  sizes=[1, 5, 16, 11], p=0.3, onehot=True, seed=21, linkpred=False, bias_scale=0.0)
+    softpool_case("g5_softpool_n16_f3_link", B=4, N=16, F_=3, H=8, E=8, C=6, ratio=0.25,
+                  sizes=[1, 5, 16, 11], p=0.3, onehot=True, seed=21, linkpred=True, bias_scale=0.15)
+    softpool_case("g4_softpool_n100_f89", B=4, N=100, F_=89, H=20, E=20, C=2, ratio=0.1,
+                  sizes=[100, 37, 1, 64], p=0.06, onehot=True, seed=22, linkpred=False, bias_scale=0.1)
+    softpool_case("g5_softpool_n100_f89_link", B=4, N=100, F_=89, H=20, E=20, C=2, ratio=0.1,
+                  sizes=[100, 37, 1, 64], p=0.06, onehot=True, seed=22, linkpred=True, bias_scale=0.1)
+
+
+# =========================================================================== G6
+def g6_base():
+    for tag, concat, bn, hidden in (("concat", True, True, []), ("addself", False, True, [10]),
+                                    ("nobn", True, False, [])):
+        B, N, F_, H, E, C = 4, 20, 7, 12, 10, 3
+        x, adj, nn_, label = O.make_batch(B, N, F_, n_min=2, sizes=[20, 3, 11, 17], p=0.25, seed=31,
+                                          onehot=False, n_classes=C)
+        m = R.GcnEncoderGraph(F_, H, E, C, 3, pred_hidden_dims=hidden, concat=concat, bn=bn)
+        params = O.init_params({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=131,
+                               bias_scale=0.1)
+        load_params(m, params)
+        ypred = m(x, adj, nn_)
+        loss = m.loss(ypred, label)
+        loss.backward()
+        grads = {f"grad.{k}": p.grad for k, p in m.named_parameters()}
+        save(f"g6_base_{tag}", x=x, adj=adj, num_nodes=nn_, label=label, ypred=ypred, loss=loss,
+             cfg=np.array([int(concat), int(bn), len(hidden)]), **pack_params("param.", params), **grads)
+
+
+# =========================================================================== G7
+def g7_set2set():
+    for n in (7, 100):
+        B, d = 3, 12
+        torch.manual_seed(40 + n)
+        s2s = RS.Set2Set(d, 2 * d)
+        emb = torch.randn(B, n, d) * 0.7
+        emb[0, n // 2:, :] = 0.0        # padded rows still enter the softmax (set2set.py:51)
+        emb.requires_grad_(True)
+        out = s2s(emb)
+        g = torch.randn(out.shape, generator=torch.Generator().manual_seed(41))
+        (out * g).sum().backward()
+        params = {k: v.detach().clone() for k, v in s2s.state_dict().items()}
+        grads = {f"grad.{k}": p.grad for k, p in s2s.named_parameters()}
+        save(f"g7_set2set_n{n}", emb=emb, out=out, gout=g, gemb=emb.grad,
+             **pack_params("param.", params), **grads)
+    # whole GcnSet2SetEncoder
+    B, N, F_, H, E, C = 3, 14, 4, 6, 6, 3
+    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=2, sizes=[14, 5, 9], p=0.3, seed=45, n_classes=C)
+    torch.manual_seed(46)
+    m = R.GcnSet2SetEncoder(F_, H, E, C, 3)
+    sd = m.state_dict()
+    params = O.init_params({k: tuple(v.shape) for k, v in sd.items() if not k.startswith("s2s.lstm")},
+                           seed=146, bias_scale=0.1)
+    for k, v in sd.items():
+        if k.startswith("s2s.lstm"):
+            params[k] = v.detach().clone()
+    load_params(m, params)
+    ypred = m(x, adj, nn_)
+    loss = m.loss(ypred, label)
+    loss.backward()
+    grads = {f"grad.{k}": p.grad for k, p in m.named_parameters()}
+    save("g7_set2set_encoder", x=x, adj=adj, num_nodes=nn_, label=label, ypred=ypred, loss=loss,
+         **pack_params("param.", params), **grads)
+
+
+# =========================================================================== G8
+def g8_mean_aggregator():
+    rng = np.random.RandomState(8)
+    n_total, feat = 40, 9
+    table = torch.tensor(rng.randn(n_total, feat), dtype=torch.float32)
+    agg = RA.MeanAggregator(lambda ids: table[ids], cuda=False, gcn=False)
+    nodes = [3, 17, 0, 39, 8, 21]
+    neighs = [set(rng.choice(n_total, size=k, replace=False).tolist()) for k in (1, 4, 7, 2, 12, 3)]
+    out = agg.forward(nodes, neighs, num_sample=None)
+    indptr = np.cumsum([0] + [len(s) for s in neighs])
+    indices = np.concatenate([np.array(sorted(s)) for s in neighs])
+    save("g8_mean_aggregator", table=table, nodes=np.array(nodes), indptr=indptr, indices=indices, out=out)
+
+
+# =========================================================================== G9
+def g9_enzymes():
+    from graph_pooling_amd import tu_dataset as TU
+    datadir = os.path.join(REF, "data")
+    graphs = TU.read_tu_graphs(datadir, "ENZYMES", max_nodes=100)[:20]
+    F_ = TU.num_node_label_classes(datadir, "ENZYMES")
+    batch = TU.collate(graphs, 100, F_)
+    x, adj = torch.tensor(batch["feats"]), torch.tensor(batch["adj"])
+    nn_, label = batch["num_nodes"], torch.tensor(batch["label"])
+    m = R.SoftPoolingGcnEncoder(100, F_, 20, 20, 6, 3, 20, assign_ratio=0.1, num_pooling=1, linkpred=True)
+    params = O.init_params({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=9, bias_scale=0.05)
+    load_params(m, params)
+    ypred = m(x, adj, nn_, assign_x=x)
+    s = m.assign_tensor
+    loss = ref_loss(m, ypred, label, adj, nn_)
+    loss.backward()
+    grads = {f"grad.{k}": p.grad for k, p in m.named_parameters()}
+    # adjacency is 0/1: store bit-packed to keep the fixture small
+    save("g9_enzymes_batch", x=x, adj_bits=np.packbits(batch["adj"].astype(np.uint8), axis=-1),
+         num_nodes=nn_, label=label, ypred=ypred, assign=s, loss=loss, link_loss=m.link_loss,
+         **pack_params("param.", params), **grads)
+
+
+# ========================================================================== G10
+def g10_adam():
+    B, N, F_, H, E, C = 4, 16, 3, 8, 8, 6
+    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=1, sizes=[7, 5, 16, 11], p=0.3, seed=51, n_classes=C)
+    m = R.SoftPoolingGcnEncoder(N, F_, H, E, C, 3, H, assign_ratio=0.25, num_pooling=1, linkpred=True)
+    params = O.init_params({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=151, bias_scale=0.1)
+    load_params(m, params)
+    opt = torch.optim.Adam(m.parameters(), lr=0.001)          # train.py:173
+    losses = []
+    for _ in range(2):
+        m.zero_grad()
+        ypred = m(x, adj, nn_, assign_x=x)
+        loss = ref_loss(m, ypred, label, adj, nn_)
+        loss.backward()
+        nn.utils.clip_grad_norm_(m.parameters(), 2.0)         # train.py:209
+        opt.step()                                            # train.py:210
+        losses.append(loss.detach())
+    after = {f"after.{k}": v.detach().clone() for k, v in m.state_dict().items()}
+    save("g10_adam_two_steps", x=x, adj=adj, num_nodes=nn_, label=label, losses=torch.stack(losses),
+         **pack_params("param.", params), **after)
+
+
+def main():
+    random.seed(0)
+    np.random.seed(0)
+    g2_apply_bn()
+    g3_gcn_forward()
+    g4_g5_softpool()
+    g6_base()
+    g7_set2set()
+    g8_mean_aggregator()
+    g9_enzymes()
+    g10_adam()
+
+
+if __name__ == "__main__":
+    main()
