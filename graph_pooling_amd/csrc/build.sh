@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libdiffpool_hip.so for gfx950 (MI355X). hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libdiffpool_hip.so
+SRCS="dp_api.hip dp_gemm.hip dp_rowops.hip dp_linkpred.hip dp_model.hip dp_set2set.hip dp_meanagg.hip"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fvisibility=hidden"
+mkdir -p build
+pids=()
+for s in $SRCS; do
+  o=build/${s%.hip}.o
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ dp_common.h -nt "$o" ] || [ ../../include/diffpool_hip.h -nt "$o" ]; then
+    hipcc $FLAGS -c "$s" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/*.o
+echo "built $(realpath $OUT)"

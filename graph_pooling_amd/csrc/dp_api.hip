@@ -1,0 +1,504 @@
+// extern "C" boundary of libdiffpool_hip.so: argument checks, then the launch sequences.
+#include <cstdarg>
+
+#include "dp_common.h"
+
+namespace dp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+// dp_model.hip
+int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
+                    const float* assign_x, const int* num_nodes, float* ypred, float* assign_out, void* save);
+int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
+                     const float* assign_x, const int* num_nodes, const float* d_ypred, const float* d_assign,
+                     float* grads, const void* save);
+size_t encoder_save_bytes(const dp_encoder_cfg& c);
+int encoder_validate(const dp_encoder_cfg* c);
+// dp_set2set.hip
+void set2set_fwd(Seq& q, const float* emb, int lde, const float* w_ih, const float* w_hh, const float* b_ih,
+                 const float* b_hh, const float* Wp, const float* bp, float* out, int B, int n, int d, void* save);
+void set2set_bwd(Seq& q, const float* emb, int lde, const float* w_ih, const float* w_hh, const float* b_ih,
+                 const float* b_hh, const float* Wp, const float* bp, const float* out, const float* dout,
+                 float* demb, int ldde, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dWp,
+                 float* dbp, int B, int n, int d, const void* save);
+size_t set2set_save_bytes(int B, int n, int d);
+// dp_meanagg.hip
+void mean_aggregate_fwd(Seq& q, const float* table, int ldt, const int* indptr, const int* indices, float* out,
+                        int ldo, int n_rows, int feat);
+void mean_aggregate_bwd(Seq& q, const float* dout, int ldo, const int* indptr, const int* indices, float* dtable,
+                        int ldt, int n_rows, int feat);
+
+namespace {
+
+RowGroups one_group(int w) {
+    RowGroups g{};
+    g.G = 1;
+    g.c0[0] = 0;
+    g.w[0] = w;
+    return g;
+}
+GroupPtrs gp(float* p, int ld) {
+    GroupPtrs r{};
+    r.p[0] = p;
+    r.ld[0] = ld;
+    return r;
+}
+GroupCPtrs gcp(const float* p, int ld) {
+    GroupCPtrs r{};
+    r.p[0] = p;
+    r.ld[0] = ld;
+    return r;
+}
+
+// ---- op-level sequences (each usable in dry mode for workspace sizing)
+void gcn_layer_fwd_seq(Seq& q, const float* x, int ldx, const float* adj, const float* W, const float* bias, float* y,
+                       int ldy, float* invn, int B, int n, int Fin, int Fout, int flags) {
+    float* P = q.alloc<float>((size_t)B * n * Fout);
+    float* U = q.alloc<float>((size_t)B * n * Fout);
+    if (q.err) return;
+    bgemm(q, x, W, P, nullptr, B, n, Fout, Fin, ldx, Fout, Fout, (long)n * ldx, 0, (long)n * Fout, false, false, 1.f,
+          0.f, 0);
+    bgemm(q, adj, P, U, nullptr, B, n, Fout, n, n, Fout, Fout, (long)n * n, (long)n * Fout, (long)n * Fout, false,
+          false, 1.f, 0.f, 0);
+    rownorm_fwd(q, U, Fout, (flags & DP_F_ADD_SELF) ? P : nullptr, gcp(bias, 0), one_group(Fout), gp(y, ldy), invn,
+                nullptr, (long)B * n, (flags & DP_F_NORMALIZE) ? 1 : 0, 0);
+}
+
+void gcn_layer_bwd_seq(Seq& q, const float* x, int ldx, const float* adj, const float* W, const float* y, int ldy,
+                       const float* invn, const float* dy, int lddy, float* dx, int lddx, float* dW, float* db,
+                       float* dadj, int B, int n, int Fin, int Fout, int flags) {
+    float* dU = q.alloc<float>((size_t)B * n * Fout);
+    float* G = q.alloc<float>((size_t)B * n * Fout);
+    float* P = dadj ? q.alloc<float>((size_t)B * n * Fout) : nullptr;
+    if (q.err) return;
+    const int norm = (flags & DP_F_NORMALIZE) ? 1 : 0;
+    rownorm_bwd(q, gcp(dy, lddy), gcp(nullptr, 0), gcp(y, ldy), invn, nullptr, nullptr, one_group(Fout), dU, Fout, B, n,
+                0, 0, norm);
+    if (db) colsum_batched(q, dU, Fout, 0, B * n, Fout, db, 0, 1);
+    bgemm(q, adj, dU, G, nullptr, B, n, Fout, n, n, Fout, Fout, (long)n * n, (long)n * Fout, (long)n * Fout, true, false,
+          1.f, 0.f, 0);
+    if (flags & DP_F_ADD_SELF) axpy(q, G, dU, 1.f, (long)B * n * Fout);
+    // dW = sum_b x_b^T G_b: one contraction over K = B*n rows (x rows of consecutive graphs are ldx apart)
+    bgemm(q, x, G, dW, nullptr, 1, Fin, Fout, B * n, ldx, Fout, Fout, 0, 0, 0, true, false, 1.f, 0.f, 0);
+    if (dx)
+        bgemm(q, G, W, dx, nullptr, B, n, Fin, Fout, Fout, Fout, lddx, (long)n * Fout, 0, (long)n * lddx, false, true,
+              1.f, 0.f, 0);
+    if (dadj) {
+        bgemm(q, x, W, P, nullptr, B, n, Fout, Fin, ldx, Fout, Fout, (long)n * ldx, 0, (long)n * Fout, false, false,
+              1.f, 0.f, 0);
+        bgemm(q, dU, P, dadj, nullptr, B, n, n, Fout, Fout, Fout, n, (long)n * Fout, (long)n * Fout, (long)n * n, false,
+              true, 1.f, 0.f, 0);
+    }
+}
+
+void bn_fwd_seq(Seq& q, const float* x, int ldx, float* y, int ldy, float* stats, int B, int n, int F, int relu) {
+    float* part = q.alloc<float>((size_t)B * n * 2);
+    float* tmp = q.alloc<float>((size_t)B * n * F);
+    if (q.err) return;
+    RowGroups g = one_group(F);
+    rownorm_fwd(q, x, ldx, nullptr, gcp(nullptr, 0), g, gp(tmp, F), nullptr, part, (long)B * n, 0, relu ? 1 : 2);
+    bn_finalize(q, part, stats, B, n, g);
+    bn_apply_fwd(q, tmp, F, stats, g, gp(y, ldy), B, n, relu);
+}
+
+void bn_bwd_seq(Seq& q, const float* x, int ldx, const float* y, int ldy, const float* stats, const float* dy, int lddy,
+                float* dx, int lddx, int B, int n, int F, int relu) {
+    float* part = q.alloc<float>((size_t)B * n * 2);
+    float* means = q.alloc<float>((size_t)n * 2);
+    float* ones = q.alloc<float>((size_t)B * n);   // unused invn slot (normalize = 0)
+    (void)ones;
+    if (q.err) return;
+    RowGroups g = one_group(F);
+    bn_bwd_partials(q, gcp(dy, lddy), gcp(y, ldy), g, part, (long)B * n);
+    sum_finalize(q, part, means, B, n, g);
+    // "y" operand of rownorm_bwd is only used for the ReLU mask: the forward input x
+    rownorm_bwd(q, gcp(dy, lddy), gcp(y, ldy), gcp(relu ? x : y, relu ? ldx : ldy), nullptr, stats, means, g, dx, lddx,
+                B, n, relu, 1, 0);
+}
+
+void assign_fwd_seq(Seq& q, const float* z, int ldz, const float* Wp, const float* bp, const int* num_nodes, float* S,
+                    int B, int n, int Din, int K) {
+    float* logits = q.alloc<float>((size_t)B * n * K);
+    if (q.err) return;
+    bgemm(q, z, Wp, logits, bp, B, n, K, Din, ldz, Din, K, (long)n * ldz, 0, (long)n * K, false, true, 1.f, 0.f, 0);
+    softmax_mask_fwd(q, logits, K, S, K, num_nodes, B, n, K);
+}
+
+void assign_bwd_seq(Seq& q, const float* z, int ldz, const float* Wp, const float* S, const float* dS,
+                    const int* num_nodes, float* dz, int lddz, float* dWp, float* dbp, int B, int n, int Din, int K) {
+    float* dlog = q.alloc<float>((size_t)B * n * K);
+    if (q.err) return;
+    softmax_mask_bwd(q, S, K, dS, K, num_nodes, dlog, K, B, n, K);
+    bgemm(q, dlog, z, dWp, nullptr, 1, K, Din, B * n, K, ldz, Din, 0, 0, 0, true, false, 1.f, 0.f, 0);
+    if (dbp) colsum_batched(q, dlog, K, 0, B * n, K, dbp, 0, 1);
+    if (dz)
+        bgemm(q, dlog, Wp, dz, nullptr, B, n, Din, K, K, Din, lddz, (long)n * K, 0, (long)n * lddz, false, false, 1.f,
+              0.f, 0);
+}
+
+void pool_fwd_seq(Seq& q, const float* S, const float* Z, int ldz, const float* adj, float* Xp, float* Ap, float* T,
+                  int B, int n, int K, int D) {
+    bgemm(q, S, Z, Xp, nullptr, B, K, D, n, K, ldz, D, (long)n * K, (long)n * ldz, (long)K * D, true, false, 1.f, 0.f,
+          0);
+    bgemm(q, S, adj, T, nullptr, B, K, n, n, K, n, n, (long)n * K, (long)n * n, (long)K * n, true, false, 1.f, 0.f, 0);
+    bgemm(q, T, S, Ap, nullptr, B, K, K, n, n, K, K, (long)K * n, (long)n * K, (long)K * K, false, false, 1.f, 0.f, 0);
+}
+
+void pool_bwd_seq(Seq& q, const float* S, const float* Z, int ldz, const float* adj, const float* T, const float* dXp,
+                  const float* dAp, float* dS, float* dZ, int lddz, float* dadj, int B, int n, int K, int D) {
+    float* V = q.alloc<float>((size_t)B * n * K);
+    if (q.err) return;
+    bgemm(q, S, dXp, dZ, nullptr, B, n, D, K, K, D, lddz, (long)n * K, (long)K * D, (long)n * lddz, false, false, 1.f,
+          1.f, 0);
+    bgemm(q, Z, dXp, dS, nullptr, B, n, K, D, ldz, D, K, (long)n * ldz, (long)K * D, (long)n * K, false, true, 1.f, 0.f,
+          0);
+    bgemm(q, T, dAp, dS, nullptr, B, n, K, K, n, K, K, (long)K * n, (long)K * K, (long)n * K, true, false, 1.f, 1.f, 0);
+    bgemm(q, S, dAp, V, nullptr, B, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, true, 1.f, 0.f, 0);
+    bgemm(q, adj, V, dS, nullptr, B, n, K, n, n, K, K, (long)n * n, (long)n * K, (long)n * K, false, false, 1.f, 1.f, 0);
+    if (dadj) {
+        bgemm(q, S, dAp, V, nullptr, B, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, false, 1.f, 0.f,
+              0);
+        bgemm(q, V, S, dadj, nullptr, B, n, n, K, K, K, n, (long)n * K, (long)n * K, (long)n * n, false, true, 1.f, 1.f,
+              0);
+    }
+}
+
+void loss_fwd_seq(Seq& q, const float* ypred, const long long* label, const float* S, const float* adj,
+                  const int* num_nodes, float* loss_out, float* prob, int B, int C, int N, int K, int linkpred);
+void loss_bwd_seq(Seq& q, const float* prob, const long long* label, const float* S, const float* adj,
+                  const int* num_nodes, const float* dloss, float* d_ypred, float* dS, int B, int C, int N, int K,
+                  int linkpred) {
+    ce_bwd(q, prob, label, dloss, 1.f, d_ypred, B, C);
+    if (linkpred) linkpred_bwd(q, S, K, adj, num_nodes, dloss, dS, K, B, N, K, 0);
+}
+
+__global__ void k_add2(float* out, const float* a, const float* b) { out[0] = a[0] + b[0]; out[1] = b[0]; }
+__global__ void k_set2(float* out, const float* a) { out[0] = a[0]; out[1] = 0.f; }
+
+void loss_fwd_seq(Seq& q, const float* ypred, const long long* label, const float* S, const float* adj,
+                  const int* num_nodes, float* loss_out, float* prob, int B, int C, int N, int K, int linkpred) {
+    float* tmp = q.alloc<float>(64);
+    if (q.err) return;
+    ce_fwd(q, ypred, label, tmp, prob, B, C);
+    if (linkpred) {
+        linkpred_fwd(q, S, K, adj, num_nodes, tmp + 1, B, N, K);
+        if (q.ok()) {
+            hipLaunchKernelGGL(k_add2, dim3(1), dim3(1), 0, q.stream, loss_out, tmp, tmp + 1);
+            q.check_launch("loss_add");
+        }
+    } else if (q.ok()) {
+        hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, q.stream, loss_out, tmp);
+        q.check_launch("loss_set");
+    }
+}
+
+template <typename F>
+size_t sized(F&& f) {
+    Seq q = Seq::sizing();
+    f(q);
+    return q.ws_off + 256;
+}
+
+}  // namespace
+}  // namespace dp
+
+using namespace dp;
+
+#define STREAM(s) ((hipStream_t)(s))
+#define NONNEG(v) DP_CHECK_ARG((v) > 0, #v "=%d must be positive", (int)(v))
+#define NOTNULL(p) DP_CHECK_ARG((p) != nullptr, #p " is NULL")
+
+extern "C" {
+
+int dp_version(void) { return DP_VERSION; }
+const char* dp_last_error_string(void) { return dp::last_error(); }
+
+int dp_bgemm_f32(const float* A, const float* B, float* C, const float* bias, int batch, int M, int N, int K,
+                 int lda, int ldb, int ldc, long strideA, long strideB, long strideC, int transA, int transB,
+                 float alpha, float beta, int act, void* stream) {
+    NOTNULL(A); NOTNULL(B); NOTNULL(C);
+    NONNEG(batch); NONNEG(M); NONNEG(N);
+    DP_CHECK_ARG(K >= 0, "K=%d must be >= 0", K);
+    DP_CHECK_ARG(lda >= (transA ? M : K), "lda=%d too small", lda);
+    DP_CHECK_ARG(ldb >= (transB ? K : N), "ldb=%d too small", ldb);
+    DP_CHECK_ARG(ldc >= N, "ldc=%d < N=%d", ldc, N);
+    Seq q(STREAM(stream), nullptr, 0);
+    bgemm(q, A, B, C, bias, batch, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, transA != 0, transB != 0, alpha,
+          beta, act);
+    return q.err;
+}
+
+size_t dp_gcn_layer_workspace_bytes(int B, int n, int Fin, int Fout) {
+    size_t f = sized([&](Seq& q) { gcn_layer_fwd_seq(q, 0, Fin, 0, 0, 0, 0, Fout, 0, B, n, Fin, Fout, 0); });
+    size_t b = sized([&](Seq& q) {
+        gcn_layer_bwd_seq(q, 0, Fin, 0, 0, 0, Fout, 0, 0, Fout, 0, Fin, 0, 0, (float*)1, B, n, Fin, Fout, 0);
+    });
+    return f > b ? f : b;
+}
+int dp_gcn_layer_fwd(const float* x, int ldx, const float* adj, const float* W, const float* bias, float* y, int ldy,
+                     float* invnorm, int B, int n, int Fin, int Fout, int flags, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    NOTNULL(x); NOTNULL(adj); NOTNULL(W); NOTNULL(y);
+    NONNEG(B); NONNEG(n); NONNEG(Fin); NONNEG(Fout);
+    DP_CHECK_ARG(ldx >= Fin && ldy >= Fout, "ldx=%d/ldy=%d smaller than the row width", ldx, ldy);
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    gcn_layer_fwd_seq(q, x, ldx, adj, W, bias, y, ldy, invnorm, B, n, Fin, Fout, flags);
+    return q.err;
+}
+int dp_gcn_layer_bwd(const float* x, int ldx, const float* adj, const float* W, const float* y, int ldy,
+                     const float* invnorm, const float* dy, int lddy, float* dx, int lddx, float* dW, float* db,
+                     float* dadj, int B, int n, int Fin, int Fout, int flags, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+    NOTNULL(x); NOTNULL(adj); NOTNULL(W); NOTNULL(y); NOTNULL(dy); NOTNULL(dW);
+    NONNEG(B); NONNEG(n); NONNEG(Fin); NONNEG(Fout);
+    DP_CHECK_ARG(!(flags & DP_F_NORMALIZE) || invnorm, "invnorm is NULL but DP_F_NORMALIZE is set");
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    gcn_layer_bwd_seq(q, x, ldx, adj, W, y, ldy, invnorm, dy, lddy, dx, lddx, dW, db, dadj, B, n, Fin, Fout, flags);
+    return q.err;
+}
+
+size_t dp_bn_node_workspace_bytes(int B, int n, int F) {
+    size_t f = sized([&](Seq& q) { bn_fwd_seq(q, 0, F, 0, F, 0, B, n, F, 1); });
+    size_t b = sized([&](Seq& q) { bn_bwd_seq(q, 0, F, 0, F, 0, 0, F, 0, F, B, n, F, 1); });
+    return f > b ? f : b;
+}
+int dp_bn_node_fwd(const float* x, int ldx, float* y, int ldy, float* stats, int B, int n, int F, int relu,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+    NOTNULL(x); NOTNULL(y); NOTNULL(stats);
+    NONNEG(B); NONNEG(n); NONNEG(F);
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    bn_fwd_seq(q, x, ldx, y, ldy, stats, B, n, F, relu);
+    return q.err;
+}
+int dp_bn_node_bwd(const float* x, int ldx, const float* y, int ldy, const float* stats, const float* dy, int lddy,
+                   float* dx, int lddx, int B, int n, int F, int relu, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+    NOTNULL(y); NOTNULL(stats); NOTNULL(dy); NOTNULL(dx);
+    DP_CHECK_ARG(!relu || x, "x is NULL but relu != 0");
+    NONNEG(B); NONNEG(n); NONNEG(F);
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    bn_bwd_seq(q, x, ldx, y, ldy, stats, dy, lddy, dx, lddx, B, n, F, relu);
+    return q.err;
+}
+
+size_t dp_assign_workspace_bytes(int B, int n, int Din, int K) {
+    return sized([&](Seq& q) { assign_fwd_seq(q, 0, Din, 0, 0, 0, 0, B, n, Din, K); });
+}
+int dp_assign_softmax_mask_fwd(const float* z, int ldz, const float* Wp, const float* bp, const int* num_nodes,
+                               float* S, int B, int n, int Din, int K, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    NOTNULL(z); NOTNULL(Wp); NOTNULL(S);
+    NONNEG(B); NONNEG(n); NONNEG(Din); NONNEG(K);
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    assign_fwd_seq(q, z, ldz, Wp, bp, num_nodes, S, B, n, Din, K);
+    return q.err;
+}
+int dp_assign_softmax_mask_bwd(const float* z, int ldz, const float* Wp, const float* S, const float* dS,
+                               const int* num_nodes, float* dz, int lddz, float* dWp, float* dbp, int B, int n, int Din,
+                               int K, void* workspace, size_t workspace_bytes, void* stream) {
+    NOTNULL(z); NOTNULL(Wp); NOTNULL(S); NOTNULL(dS); NOTNULL(dWp);
+    NONNEG(B); NONNEG(n); NONNEG(Din); NONNEG(K);
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    assign_bwd_seq(q, z, ldz, Wp, S, dS, num_nodes, dz, lddz, dWp, dbp, B, n, Din, K);
+    return q.err;
+}
+
+int dp_pool_fwd(const float* S, const float* Z, int ldz, const float* adj, float* Xp, float* Ap, float* T, int B, int n,
+                int K, int D, void* stream) {
+    NOTNULL(S); NOTNULL(Z); NOTNULL(adj); NOTNULL(Xp); NOTNULL(Ap); NOTNULL(T);
+    NONNEG(B); NONNEG(n); NONNEG(K); NONNEG(D);
+    Seq q(STREAM(stream), nullptr, 0);
+    pool_fwd_seq(q, S, Z, ldz, adj, Xp, Ap, T, B, n, K, D);
+    return q.err;
+}
+size_t dp_pool_bwd_workspace_bytes(int B, int n, int K, int D) {
+    return sized([&](Seq& q) { pool_bwd_seq(q, 0, 0, D, 0, 0, 0, 0, 0, 0, D, 0, B, n, K, D); });
+}
+int dp_pool_bwd(const float* S, const float* Z, int ldz, const float* adj, const float* T, const float* dXp,
+                const float* dAp, float* dS, float* dZ, int lddz, float* dadj, int B, int n, int K, int D,
+                void* workspace, size_t workspace_bytes, void* stream) {
+    NOTNULL(S); NOTNULL(Z); NOTNULL(adj); NOTNULL(T); NOTNULL(dXp); NOTNULL(dAp); NOTNULL(dS); NOTNULL(dZ);
+    NONNEG(B); NONNEG(n); NONNEG(K); NONNEG(D);
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    pool_bwd_seq(q, S, Z, ldz, adj, T, dXp, dAp, dS, dZ, lddz, dadj, B, n, K, D);
+    return q.err;
+}
+
+int dp_masked_max_fwd(const float* Z, int ldz, const int* num_nodes, float* out, int ldo, int* argmax, int B, int n,
+                      int F, void* stream) {
+    NOTNULL(Z); NOTNULL(out); NOTNULL(argmax);
+    NONNEG(B); NONNEG(n); NONNEG(F);
+    Seq q(STREAM(stream), nullptr, 0);
+    masked_max_fwd(q, Z, ldz, num_nodes, out, ldo, argmax, F, B, n, F);
+    return q.err;
+}
+int dp_masked_max_bwd(const float* dout, int ldo, const int* argmax, float* dZ, int lddz, int B, int n, int F,
+                      void* stream) {
+    NOTNULL(dout); NOTNULL(argmax); NOTNULL(dZ);
+    NONNEG(B); NONNEG(n); NONNEG(F);
+    Seq q(STREAM(stream), nullptr, 0);
+    masked_max_bwd(q, dout, ldo, argmax, F, dZ, lddz, B, n, F);
+    return q.err;
+}
+
+size_t dp_linkpred_workspace_bytes(int B, int n, int K) {
+    size_t f = sized([&](Seq& q) { linkpred_fwd(q, 0, K, 0, 0, 0, B, n, K); });
+    size_t b = sized([&](Seq& q) { linkpred_bwd(q, 0, K, 0, 0, 0, 0, K, B, n, K, 0); });
+    return f > b ? f : b;
+}
+int dp_linkpred_loss_fwd(const float* S, const float* adj, const int* num_nodes, float* loss_out, int B, int n, int K,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    NOTNULL(S); NOTNULL(adj); NOTNULL(loss_out);
+    NONNEG(B); NONNEG(n); NONNEG(K);
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    linkpred_fwd(q, S, K, adj, num_nodes, loss_out, B, n, K);
+    return q.err;
+}
+int dp_linkpred_loss_bwd(const float* S, const float* adj, const int* num_nodes, const float* dloss, float* dS,
+                         int accumulate, int B, int n, int K, void* workspace, size_t workspace_bytes, void* stream) {
+    NOTNULL(S); NOTNULL(adj); NOTNULL(dS);
+    NONNEG(B); NONNEG(n); NONNEG(K);
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    linkpred_bwd(q, S, K, adj, num_nodes, dloss, dS, K, B, n, K, accumulate);
+    return q.err;
+}
+
+int dp_cross_entropy_fwd(const float* logits, const long long* label, float* loss_out, float* prob, int B, int C,
+                         void* stream) {
+    NOTNULL(logits); NOTNULL(label); NOTNULL(loss_out);
+    NONNEG(B); NONNEG(C);
+    Seq q(STREAM(stream), nullptr, 0);
+    ce_fwd(q, logits, label, loss_out, prob, B, C);
+    return q.err;
+}
+int dp_cross_entropy_bwd(const float* prob, const long long* label, const float* dloss, float* dlogits, int B, int C,
+                         void* stream) {
+    NOTNULL(prob); NOTNULL(label); NOTNULL(dlogits);
+    NONNEG(B); NONNEG(C);
+    Seq q(STREAM(stream), nullptr, 0);
+    ce_bwd(q, prob, label, dloss, 1.f, dlogits, B, C);
+    return q.err;
+}
+
+size_t dp_set2set_save_bytes(int B, int n, int d) { return set2set_save_bytes(B, n, d); }
+int dp_set2set_fwd(const float* emb, int lde, const float* w_ih, const float* w_hh, const float* b_ih,
+                   const float* b_hh, const float* Wp, const float* bp, float* out, int B, int n, int d, void* save,
+                   size_t save_bytes, void* stream) {
+    NOTNULL(emb); NOTNULL(w_ih); NOTNULL(w_hh); NOTNULL(b_ih); NOTNULL(b_hh); NOTNULL(Wp); NOTNULL(bp); NOTNULL(out);
+    NONNEG(B); NONNEG(n); NONNEG(d);
+    DP_CHECK_ARG(!save || save_bytes >= set2set_save_bytes(B, n, d), "set2set save buffer too small: %zu < %zu",
+                 save_bytes, set2set_save_bytes(B, n, d));
+    Seq q(STREAM(stream), nullptr, 0);
+    set2set_fwd(q, emb, lde, w_ih, w_hh, b_ih, b_hh, Wp, bp, out, B, n, d, save);
+    return q.err;
+}
+size_t dp_set2set_bwd_workspace_bytes(int B, int n, int d) {
+    return sized([&](Seq& q) {
+        set2set_bwd(q, 0, d, 0, 0, 0, 0, 0, 0, 0, 0, 0, d, 0, 0, 0, 0, 0, 0, B, n, d, 0);
+    });
+}
+int dp_set2set_bwd(const float* emb, int lde, const float* w_ih, const float* w_hh, const float* b_ih,
+                   const float* b_hh, const float* Wp, const float* bp, const float* out, const float* dout,
+                   float* demb, int ldde, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dWp,
+                   float* dbp, int B, int n, int d, const void* save, size_t save_bytes, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    NOTNULL(emb); NOTNULL(w_ih); NOTNULL(w_hh); NOTNULL(Wp); NOTNULL(out); NOTNULL(dout); NOTNULL(demb);
+    NOTNULL(dw_ih); NOTNULL(dw_hh); NOTNULL(db_ih); NOTNULL(db_hh); NOTNULL(dWp); NOTNULL(dbp); NOTNULL(save);
+    NONNEG(B); NONNEG(n); NONNEG(d);
+    DP_CHECK_ARG(save_bytes >= set2set_save_bytes(B, n, d), "set2set save buffer too small");
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    set2set_bwd(q, emb, lde, w_ih, w_hh, b_ih, b_hh, Wp, bp, out, dout, demb, ldde, dw_ih, dw_hh, db_ih, db_hh, dWp,
+                dbp, B, n, d, save);
+    return q.err;
+}
+
+int dp_mean_aggregate_fwd(const float* table, int ldt, const int* indptr, const int* indices, float* out, int ldo,
+                          int n_rows, int feat, void* stream) {
+    NOTNULL(table); NOTNULL(indptr); NOTNULL(indices); NOTNULL(out);
+    NONNEG(n_rows); NONNEG(feat);
+    Seq q(STREAM(stream), nullptr, 0);
+    mean_aggregate_fwd(q, table, ldt, indptr, indices, out, ldo, n_rows, feat);
+    return q.err;
+}
+int dp_mean_aggregate_bwd(const float* dout, int ldo, const int* indptr, const int* indices, float* dtable, int ldt,
+                          int n_rows, int feat, void* stream) {
+    NOTNULL(dout); NOTNULL(indptr); NOTNULL(indices); NOTNULL(dtable);
+    NONNEG(n_rows); NONNEG(feat);
+    Seq q(STREAM(stream), nullptr, 0);
+    mean_aggregate_bwd(q, dout, ldo, indptr, indices, dtable, ldt, n_rows, feat);
+    return q.err;
+}
+
+// ------------------------------------------------------------------ model level
+size_t dp_sizeof_encoder_cfg(void) { return sizeof(dp_encoder_cfg); }
+size_t dp_encoder_save_bytes(const dp_encoder_cfg* cfg) {
+    if (encoder_validate(cfg) != DP_OK) return 0;
+    return encoder_save_bytes(*cfg) + 256;
+}
+size_t dp_encoder_workspace_bytes(const dp_encoder_cfg* cfg) {
+    if (encoder_validate(cfg) != DP_OK) return 0;
+    size_t f = sized([&](Seq& q) { encoder_forward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0); });
+    size_t b = sized([&](Seq& q) { encoder_backward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0); });
+    return f > b ? f : b;
+}
+int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
+                       const float* assign_x, const int* num_nodes, float* ypred, float* assign_out, void* save,
+                       size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = encoder_validate(cfg);
+    if (rc != DP_OK) return rc;
+    NOTNULL(params); NOTNULL(x); NOTNULL(adj); NOTNULL(ypred); NOTNULL(save);
+    DP_CHECK_ARG(cfg->num_pooling == 0 || assign_x, "assign_x is NULL");
+    DP_CHECK_ARG(save_bytes >= encoder_save_bytes(*cfg), "save buffer too small: %zu < %zu", save_bytes,
+                 encoder_save_bytes(*cfg));
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    return encoder_forward(q, *cfg, params, x, adj, assign_x, num_nodes, ypred, assign_out, save);
+}
+int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
+                        const float* assign_x, const int* num_nodes, const float* d_ypred, const float* d_assign,
+                        float* grads, const void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    int rc = encoder_validate(cfg);
+    if (rc != DP_OK) return rc;
+    NOTNULL(params); NOTNULL(x); NOTNULL(adj); NOTNULL(d_ypred); NOTNULL(grads); NOTNULL(save);
+    DP_CHECK_ARG(save_bytes >= encoder_save_bytes(*cfg), "save buffer too small: %zu < %zu", save_bytes,
+                 encoder_save_bytes(*cfg));
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    return encoder_backward(q, *cfg, params, x, adj, assign_x, num_nodes, d_ypred, d_assign, grads, save);
+}
+
+size_t dp_loss_workspace_bytes(int B, int N, int K, int linkpred) {
+    size_t f = sized([&](Seq& q) { loss_fwd_seq(q, 0, 0, 0, 0, 0, 0, 0, B, 1, N, K, linkpred); });
+    size_t b = sized([&](Seq& q) { loss_bwd_seq(q, 0, 0, 0, 0, 0, 0, 0, 0, B, 1, N, K, linkpred); });
+    return f > b ? f : b;
+}
+int dp_loss_forward(const float* ypred, const long long* label, const float* S, const float* adj, const int* num_nodes,
+                    float* loss_out, float* prob, int B, int C, int N, int K, int linkpred, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    NOTNULL(ypred); NOTNULL(label); NOTNULL(loss_out); NOTNULL(prob);
+    NONNEG(B); NONNEG(C);
+    DP_CHECK_ARG(!linkpred || (S && adj && N > 0 && K > 0), "linkpred needs S, adj, N, K");
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    loss_fwd_seq(q, ypred, label, S, adj, num_nodes, loss_out, prob, B, C, N, K, linkpred);
+    return q.err;
+}
+int dp_loss_backward(const float* prob, const long long* label, const float* S, const float* adj, const int* num_nodes,
+                     const float* dloss, float* d_ypred, float* dS, int B, int C, int N, int K, int linkpred,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    NOTNULL(prob); NOTNULL(label); NOTNULL(d_ypred);
+    NONNEG(B); NONNEG(C);
+    DP_CHECK_ARG(!linkpred || (S && adj && dS && N > 0 && K > 0), "linkpred needs S, adj, dS, N, K");
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    loss_bwd_seq(q, prob, label, S, adj, num_nodes, dloss, d_ypred, dS, B, C, N, K, linkpred);
+    return q.err;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// Internal helpers shared by the DiffPool HIP sources (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/diffpool_hip.h"
+
+namespace dp {
+
+// ----------------------------------------------------------------- error state
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define DP_CHECK_ARG(cond, ...)                      \
+    do {                                             \
+        if (!(cond)) {                               \
+            ::dp::set_error(__VA_ARGS__);            \
+            return DP_ERR_INVALID_ARG;               \
+        }                                            \
+    } while (0)
+
+// A launch sequence records the first HIP error it meets; later launches are skipped.
+struct Seq {
+    hipStream_t stream;
+    char* ws;            // caller-owned workspace (bump allocated per call)
+    size_t ws_bytes;
+    size_t ws_off;
+    int err;             // 0, DP_ERR_* (<0) or hipError_t (>0)
+    bool dry;            // dry run: only walk the allocations (workspace sizing), launch nothing
+
+    Seq(hipStream_t s, void* w, size_t wb) : stream(s), ws((char*)w), ws_bytes(wb), ws_off(0), err(0), dry(false) {}
+    static Seq sizing() {
+        Seq q(nullptr, nullptr, ~size_t(0) >> 1);
+        q.dry = true;
+        return q;
+    }
+
+    template <typename T>
+    T* alloc(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        if (ws_off + bytes > ws_bytes) {
+            if (!err) {
+                set_error("workspace too small: need >= %zu bytes, have %zu", ws_off + bytes, ws_bytes);
+                err = DP_ERR_WORKSPACE;
+            }
+            return nullptr;
+        }
+        T* p = (T*)(ws + ws_off);   // dry run: ws == nullptr, the pointer is never dereferenced
+        ws_off += bytes;
+        return p;
+    }
+    bool ok() const { return err == 0 && !dry; }
+    void copy(void* dst, const void* src, size_t bytes) {
+        if (err || dry || bytes == 0) return;
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) {
+            set_error("hipMemcpyAsync: %s", hipGetErrorString(e));
+            err = (int)e;
+        }
+    }
+    void check_launch(const char* what) {
+        if (err) return;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            set_error("%s: %s", what, hipGetErrorString(e));
+            err = (int)e;
+        }
+    }
+    void zero(void* p, size_t bytes) {
+        if (err || dry || bytes == 0) return;
+        hipError_t e = hipMemsetAsync(p, 0, bytes, stream);
+        if (e != hipSuccess) {
+            set_error("hipMemsetAsync: %s", hipGetErrorString(e));
+            err = (int)e;
+        }
+    }
+};
+
+inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+
+// ------------------------------------------------------------- kernel launchers
+// (dp_gemm.hip)
+void bgemm(Seq& q, const float* A, const float* B, float* C, const float* bias, int batch, int M, int N,
+           int K, int lda, int ldb, int ldc, long sA, long sB, long sC, bool tA, bool tB, float alpha,
+           float beta, int act);
+
+// Column groups of a row: the level-j embed and assign GCN stacks share one pass over the
+// adjacency, so row-wise kernels work on up to two column groups of a joint buffer.
+struct RowGroups {
+    int G;               // 1 or 2
+    int c0[2];           // first column of the group in the joint buffer
+    int w[2];            // group width
+};
+struct GroupPtrs {       // per-group pointer + leading dimension (already offset to the group's first column)
+    float* p[2];
+    int ld[2];
+};
+struct GroupCPtrs {
+    const float* p[2];
+    int ld[2];
+};
+
+// (dp_rowops.hip)
+void rownorm_fwd(Seq& q, const float* U, int ldu, const float* P /*add_self or null*/, GroupCPtrs bias,
+                 RowGroups g, GroupPtrs yout, float* invn, float* part /*[rows,G,2] or null*/, long rows,
+                 int normalize, int relu_stats);
+void bn_finalize(Seq& q, const float* part, float* stats, int B, int n, RowGroups g);
+void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* stats /*null: no BN*/, RowGroups g,
+                  GroupPtrs xout, int B, int n, int relu);
+void mask_rows(Seq& q, const float* src, int lds, float* dst, int ldd, const int* num_nodes, int B, int n, int F);
+void bn_bwd_partials(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, RowGroups g, float* part, long rows);
+void sum_finalize(Seq& q, const float* part, float* means, int B, int n, RowGroups g);
+void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat /*BN output, null when no BN*/, GroupCPtrs y,
+                 const float* invn, const float* stats, const float* means, RowGroups g, float* dU, int ldu,
+                 int B, int n, int has_relu, int has_bn, int normalize);
+void colsum_batched(Seq& q, const float* X, int ldx, long strideX, int rows, int cols, float* out,
+                    long strideOut, int batch);
+void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, const int* num_nodes, int B,
+                      int n, int K);
+void softmax_mask_bwd(Seq& q, const float* S, int lds, const float* dS, int ldds, const int* num_nodes,
+                      float* dlogits, int ldl, int B, int n, int K);
+void masked_max_fwd(Seq& q, const float* Z, int ldz, const int* num_nodes, float* out, int ldo, int* argmax,
+                    int lda, int B, int n, int F);
+void masked_max_bwd(Seq& q, const float* dout, int ldo, const int* argmax, int lda, float* dZ, int ldz, int B,
+                    int n, int F);
+void relu_bwd_inplace(Seq& q, float* d, const float* h, long count);
+void ce_fwd(Seq& q, const float* logits, const long long* label, float* loss, float* prob, int B, int C);
+void ce_bwd(Seq& q, const float* prob, const long long* label, const float* dloss, float scale, float* dlogits,
+            int B, int C);
+void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, long count, int accumulate);
+void axpy(Seq& q, float* y, const float* x, float a, long count);
+
+// (dp_linkpred.hip)
+void linkpred_fwd(Seq& q, const float* S, int lds, const float* adj, const int* num_nodes, float* loss_out,
+                  int B, int n, int K);
+void linkpred_bwd(Seq& q, const float* S, int lds, const float* adj, const int* num_nodes, const float* dloss,
+                  float* dS, int ldds, int B, int n, int K, int accumulate);
+
+}  // namespace dp

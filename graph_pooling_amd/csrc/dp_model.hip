@@ -1,0 +1,561 @@
+// Model-level plans: the whole forward / backward of the DiffPool encoders as one launch sequence.
+//
+//   SoftPoolingGcnEncoder.forward   encoders.py:1231-1300   (num_pooling >= 1)
+//   GcnEncoderGraph.forward         encoders.py:1083-1122   (num_pooling == 0, readout 0)
+//   GcnSet2SetEncoder.forward       encoders.py:1144-1157   (num_pooling == 0, readout 1)
+//
+// Dataflow per pooling level j (n_j nodes, adjacency A_j, features X_j):
+//   joint GCN stacks on A_j:  embed_j(X_j) -> Z_j   and, if j < P,  assign_j(Xa_j) -> Za_j
+//       (the two stacks share every pass over A_j: their X·W products sit side by side in one
+//        [B, n_j, Ce+Ca] operand — the reference runs them as separate bmm's, encoders.py:1254,1269)
+//   readout_j = max_n Z_j                                        (:1257 / :1287)
+//   S_j = softmax(Linear_j(Za_j)) * mask (j == 0)                 (:1273-1275)
+//   X_{j+1} = S_j^T Z_j,  A_{j+1} = S_j^T A_j S_j                 (:1278-1279)
+// ypred = pred_model(cat_j readout_j)                             (:1295-1299)
+#include "dp_common.h"
+
+namespace dp {
+
+void set2set_fwd(Seq& q, const float* emb, int lde, const float* w_ih, const float* w_hh, const float* b_ih,
+                 const float* b_hh, const float* Wp, const float* bp, float* out, int B, int n, int d, void* save);
+void set2set_bwd(Seq& q, const float* emb, int lde, const float* w_ih, const float* w_hh, const float* b_ih,
+                 const float* b_hh, const float* Wp, const float* bp, const float* out, const float* dout,
+                 float* demb, int ldde, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dWp,
+                 float* dbp, int B, int n, int d, const void* save);
+size_t set2set_save_bytes(int B, int n, int d);
+
+namespace {
+
+struct LevelInfo {
+    int n, G, L;
+    const dp_stack_cfg* e;
+    const dp_stack_cfg* a;
+    int D, Da, K;
+    int ctot[DP_MAX_LAYERS];
+    int coff_e[DP_MAX_LAYERS], coff_a[DP_MAX_LAYERS];
+    int cmax;
+};
+
+LevelInfo level_info(const dp_encoder_cfg& c, int j) {
+    LevelInfo li{};
+    li.n = c.n_nodes[j];
+    li.e = &c.embed[j];
+    li.L = li.e->n_layers;
+    li.G = (j < c.num_pooling) ? 2 : 1;
+    li.a = li.G == 2 ? &c.assign[j] : nullptr;
+    li.K = li.G == 2 ? c.n_nodes[j + 1] : 0;
+    li.D = li.Da = li.cmax = 0;
+    for (int l = 0; l < li.L; ++l) {
+        li.coff_e[l] = li.D;
+        li.D += li.e->dims[l + 1];
+        li.ctot[l] = li.e->dims[l + 1];
+        if (li.a) {
+            li.coff_a[l] = li.Da;
+            li.Da += li.a->dims[l + 1];
+            li.ctot[l] += li.a->dims[l + 1];
+        }
+        if (li.ctot[l] > li.cmax) li.cmax = li.ctot[l];
+    }
+    return li;
+}
+
+// A bump allocator over the caller's save buffer (dry when base == nullptr).
+struct Bump {
+    char* base;
+    size_t off;
+    template <typename T>
+    T* take(size_t n) {
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += align256(n * sizeof(T));
+        return p;
+    }
+};
+
+struct LayerSave {
+    float* Y;      // normalised pre-ReLU output of a non-last layer, joint [B, n, ctot]
+    float* invn;   // [B, n, G]
+    float* stats;  // [n, G, 2] (mu, rstd)
+};
+struct LevelSave {
+    float* Ze;
+    float* Za;
+    LayerSave layer[DP_MAX_LAYERS];
+    float* S;
+    float* T;
+    float* Xn;
+    float* An;
+    int* argmax;
+};
+struct SaveLayout {
+    LevelSave lv[DP_MAX_LEVELS + 1];
+    float* feat;
+    float* hid[DP_MAX_PRED + 2];
+    float* Zm;
+    void* s2s;
+    size_t total;
+};
+
+int readout_width(const dp_encoder_cfg& c, const LevelInfo& li) {
+    return (c.flags & DP_F_LAST_ONLY) ? li.e->dims[li.L] : li.D;
+}
+
+SaveLayout layout_save(const dp_encoder_cfg& c, void* base) {
+    SaveLayout s{};
+    Bump b{(char*)base, 0};
+    const size_t B = c.B;
+    for (int j = 0; j <= c.num_pooling; ++j) {
+        const LevelInfo li = level_info(c, j);
+        LevelSave& lv = s.lv[j];
+        lv.Ze = b.take<float>(B * li.n * li.D);
+        lv.Za = li.a ? b.take<float>(B * li.n * li.Da) : nullptr;
+        for (int l = 0; l < li.L; ++l) {
+            lv.layer[l].Y = (l < li.L - 1) ? b.take<float>(B * li.n * li.ctot[l]) : nullptr;
+            lv.layer[l].invn = b.take<float>(B * li.n * li.G);
+            lv.layer[l].stats = (l < li.L - 1) ? b.take<float>((size_t)li.n * li.G * 2) : nullptr;
+        }
+        if (li.a) {
+            lv.S = b.take<float>(B * li.n * li.K);
+            lv.T = b.take<float>(B * li.K * li.n);
+            lv.Xn = b.take<float>(B * li.K * li.D);
+            lv.An = b.take<float>(B * li.K * li.K);
+        }
+        lv.argmax = b.take<int>(B * readout_width(c, li));
+    }
+    s.feat = b.take<float>(B * c.pred_dims[0]);
+    s.hid[0] = s.feat;
+    for (int i = 1; i < c.n_pred; ++i) s.hid[i] = b.take<float>(B * c.pred_dims[i]);
+    if (c.readout == 1) {
+        const LevelInfo li = level_info(c, 0);
+        s.Zm = b.take<float>(B * li.n * li.D);
+        s.s2s = b.take<char>(set2set_save_bytes(c.B, li.n, li.D));
+    }
+    s.total = b.off;
+    return s;
+}
+
+int validate(const dp_encoder_cfg* c) {
+    DP_CHECK_ARG(c != nullptr, "cfg is NULL");
+    DP_CHECK_ARG(c->B > 0 && c->N > 0, "B=%d N=%d must be positive", c->B, c->N);
+    DP_CHECK_ARG(c->num_pooling >= 0 && c->num_pooling <= DP_MAX_LEVELS, "num_pooling=%d out of range [0,%d]",
+                 c->num_pooling, DP_MAX_LEVELS);
+    DP_CHECK_ARG(c->n_nodes[0] == c->N, "n_nodes[0]=%d must equal N=%d", c->n_nodes[0], c->N);
+    DP_CHECK_ARG(c->n_pred >= 1 && c->n_pred <= DP_MAX_PRED + 1, "n_pred=%d out of range", c->n_pred);
+    for (int j = 0; j <= c->num_pooling; ++j) {
+        const dp_stack_cfg& e = c->embed[j];
+        DP_CHECK_ARG(e.n_layers >= 1 && e.n_layers <= DP_MAX_LAYERS, "embed[%d].n_layers=%d out of range", j,
+                     e.n_layers);
+        DP_CHECK_ARG(c->n_nodes[j] > 0, "n_nodes[%d]=%d must be positive (assign_ratio too small?)", j,
+                     c->n_nodes[j]);
+        for (int l = 0; l <= e.n_layers; ++l) DP_CHECK_ARG(e.dims[l] > 0, "embed[%d].dims[%d] must be > 0", j, l);
+        if (j < c->num_pooling) {
+            const dp_stack_cfg& a = c->assign[j];
+            DP_CHECK_ARG(a.n_layers == e.n_layers,
+                         "assign[%d].n_layers=%d must equal embed n_layers=%d (the reference's assign_pred "
+                         "input width assumes it, encoders.py:1209)", j, a.n_layers, e.n_layers);
+            DP_CHECK_ARG(a.dims[a.n_layers] == c->n_nodes[j + 1], "assign[%d] output width %d != n_nodes[%d]=%d", j,
+                         a.dims[a.n_layers], j + 1, c->n_nodes[j + 1]);
+            for (int l = 0; l <= a.n_layers; ++l)
+                DP_CHECK_ARG(a.dims[l] > 0, "assign[%d].dims[%d] must be > 0", j, l);
+        }
+    }
+    if (c->readout == 1) DP_CHECK_ARG(c->num_pooling == 0, "Set2Set readout requires num_pooling == 0");
+    {
+        int feat = 0;
+        for (int j = 0; j <= c->num_pooling; ++j) {
+            const LevelInfo li = level_info(*c, j);
+            if (j >= 1) {
+                const LevelInfo lp = level_info(*c, j - 1);
+                DP_CHECK_ARG(c->embed[j].dims[0] == lp.D, "embed[%d] input width %d != pooled feature width %d", j,
+                             c->embed[j].dims[0], lp.D);
+                if (j < c->num_pooling)
+                    DP_CHECK_ARG(c->assign[j].dims[0] == lp.D, "assign[%d] input width %d != pooled feature width %d",
+                                 j, c->assign[j].dims[0], lp.D);
+            }
+            feat += readout_width(*c, li);
+        }
+        DP_CHECK_ARG(c->pred_dims[0] == feat, "pred_dims[0]=%d != readout width %d", c->pred_dims[0], feat);
+    }
+    DP_CHECK_ARG(c->n_graph_params >= 0 && c->n_graph_params <= c->n_params, "n_graph_params out of range");
+    return DP_OK;
+}
+
+inline const float* PW(const float* params, long off) { return off >= 0 ? params + off : nullptr; }
+inline float* PWm(float* params, long off) { return off >= 0 ? params + off : nullptr; }
+
+RowGroups groups_of(const LevelInfo& li, int l) {
+    RowGroups g{};
+    g.G = li.G;
+    g.c0[0] = 0;
+    g.w[0] = li.e->dims[l + 1];
+    g.c0[1] = li.e->dims[l + 1];
+    g.w[1] = li.a ? li.a->dims[l + 1] : 0;
+    return g;
+}
+
+struct LevelIO {
+    const float* x0e;  // embed stack input [B, n, dims_e[0]]
+    const float* x0a;  // assign stack input [B, n, dims_a[0]]
+    const float* adj;  // [B, n, n]
+};
+
+// P = [x_e W_e | x_a W_a]  for layer l of level li
+void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
+               const float* params, int l, float* Pj) {
+    const int ct = li.ctot[l];
+    const int B = c.B, n = li.n;
+    for (int g = 0; g < li.G; ++g) {
+        const dp_stack_cfg* st = g == 0 ? li.e : li.a;
+        const int din = st->dims[l], dout = st->dims[l + 1];
+        const float* xin;
+        int ldin;
+        if (l == 0) {
+            xin = g == 0 ? io.x0e : io.x0a;
+            ldin = din;
+        } else {
+            xin = (g == 0 ? lv.Ze + li.coff_e[l - 1] : lv.Za + li.coff_a[l - 1]);
+            ldin = g == 0 ? li.D : li.Da;
+        }
+        const int c0 = g == 0 ? 0 : li.e->dims[l + 1];
+        bgemm(q, xin, PW(params, st->w_off[l]), Pj + c0, nullptr, B, n, dout, din, ldin, dout, ct, (long)n * ldin,
+              0, (long)n * ct, false, false, 1.f, 0.f, 0);
+    }
+}
+
+void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
+                   const float* params, float* Pj, float* Uj, float* part) {
+    const int B = c.B, n = li.n;
+    const bool bn = c.flags & DP_F_BN;
+    const bool add_self = c.flags & DP_F_ADD_SELF;
+    for (int l = 0; l < li.L; ++l) {
+        const int ct = li.ctot[l];
+        const bool last = l == li.L - 1;
+        transform(q, c, li, lv, io, params, l, Pj);
+        bgemm(q, io.adj, Pj, Uj, nullptr, B, n, ct, n, n, ct, ct, (long)n * n, (long)n * ct, (long)n * ct, false,
+              false, 1.f, 0.f, 0);
+        RowGroups g = groups_of(li, l);
+        GroupCPtrs bias{};
+        bias.p[0] = PW(params, li.e->b_off[l]);
+        bias.p[1] = li.a ? PW(params, li.a->b_off[l]) : nullptr;
+        GroupPtrs yout{};
+        if (last) {
+            yout.p[0] = lv.Ze + li.coff_e[l];
+            yout.ld[0] = li.D;
+            yout.p[1] = li.a ? lv.Za + li.coff_a[l] : nullptr;
+            yout.ld[1] = li.Da;
+        } else {
+            yout.p[0] = lv.layer[l].Y;
+            yout.ld[0] = ct;
+            yout.p[1] = lv.layer[l].Y + g.c0[1];
+            yout.ld[1] = ct;
+        }
+        const int stats_mode = (!last && bn) ? 1 : 0;
+        rownorm_fwd(q, Uj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn, stats_mode ? part : nullptr,
+                    (long)B * n, 1, stats_mode);
+        if (!last) {
+            if (bn) bn_finalize(q, part, lv.layer[l].stats, B, n, g);
+            GroupPtrs xout{};
+            xout.p[0] = lv.Ze + li.coff_e[l];
+            xout.ld[0] = li.D;
+            xout.p[1] = li.a ? lv.Za + li.coff_a[l] : nullptr;
+            xout.ld[1] = li.Da;
+            bn_apply_fwd(q, lv.layer[l].Y, ct, bn ? lv.layer[l].stats : nullptr, g, xout, B, n, 1);
+        }
+    }
+}
+
+struct LevelGrad {
+    float* dZe;    // [B, n, D]
+    float* dZa;    // [B, n, Da]
+    float* dX0;    // [B, n, dims_e[0]] gradient w.r.t. the level input (levels >= 1), accumulated
+    float* dAdj;   // [B, n, n] (levels >= 1), accumulated
+};
+
+void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
+                    const float* params, const LevelGrad& gr, float* slabs, long slab_stride, float* Pj, float* dUj,
+                    float* Gj, float* part, float* means) {
+    const int B = c.B, n = li.n;
+    const bool bn = c.flags & DP_F_BN;
+    const bool add_self = c.flags & DP_F_ADD_SELF;
+    for (int l = li.L - 1; l >= 0; --l) {
+        const int ct = li.ctot[l];
+        const bool last = l == li.L - 1;
+        RowGroups g = groups_of(li, l);
+        GroupCPtrs dx{}, xhat{}, y{};
+        dx.p[0] = gr.dZe + li.coff_e[l];
+        dx.ld[0] = li.D;
+        xhat.p[0] = lv.Ze + li.coff_e[l];
+        xhat.ld[0] = li.D;
+        if (li.a) {
+            dx.p[1] = gr.dZa + li.coff_a[l];
+            dx.ld[1] = li.Da;
+            xhat.p[1] = lv.Za + li.coff_a[l];
+            xhat.ld[1] = li.Da;
+        }
+        if (last) {
+            y = xhat;
+        } else {
+            y.p[0] = lv.layer[l].Y;
+            y.ld[0] = ct;
+            y.p[1] = lv.layer[l].Y + g.c0[1];
+            y.ld[1] = ct;
+        }
+        const bool has_bn = !last && bn;
+        if (has_bn) {
+            bn_bwd_partials(q, dx, xhat, g, part, (long)B * n);
+            sum_finalize(q, part, means, B, n, g);
+        }
+        rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, means, g, dUj, ct, B, n, !last, has_bn, 1);
+        // bias gradients (per-graph column sums into the slabs)
+        for (int gi = 0; gi < li.G; ++gi) {
+            const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
+            if (st->b_off[l] >= 0)
+                colsum_batched(q, dUj + g.c0[gi], ct, (long)n * ct, n, g.w[gi], slabs + st->b_off[l], slab_stride, B);
+        }
+        // G = A^T dU (+ dU)
+        bgemm(q, io.adj, dUj, Gj, nullptr, B, n, ct, n, n, ct, ct, (long)n * n, (long)n * ct, (long)n * ct, true, false,
+              1.f, 0.f, 0);
+        if (add_self) axpy(q, Gj, dUj, 1.f, (long)B * n * ct);
+        for (int gi = 0; gi < li.G; ++gi) {
+            const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
+            const int din = st->dims[l], dout = st->dims[l + 1];
+            const float* xin;
+            int ldin;
+            if (l == 0) {
+                xin = gi == 0 ? io.x0e : io.x0a;
+                ldin = din;
+            } else {
+                xin = gi == 0 ? lv.Ze + li.coff_e[l - 1] : lv.Za + li.coff_a[l - 1];
+                ldin = gi == 0 ? li.D : li.Da;
+            }
+            // dW slab[b] = x_in[b]^T G[b]
+            bgemm(q, xin, Gj + g.c0[gi], slabs + st->w_off[l], nullptr, B, din, dout, n, ldin, ct, dout,
+                  (long)n * ldin, (long)n * ct, slab_stride, true, false, 1.f, 0.f, 0);
+            // gradient w.r.t. the layer input: G W^T
+            float* dxin = nullptr;
+            int lddx = 0;
+            if (l > 0) {
+                dxin = gi == 0 ? gr.dZe + li.coff_e[l - 1] : gr.dZa + li.coff_a[l - 1];
+                lddx = gi == 0 ? li.D : li.Da;
+            } else if (gr.dX0) {
+                dxin = gr.dX0;
+                lddx = din;
+            }
+            if (dxin)
+                bgemm(q, Gj + g.c0[gi], PW(params, st->w_off[l]), dxin, nullptr, B, n, din, dout, ct, dout, lddx,
+                      (long)n * ct, 0, (long)n * lddx, false, true, 1.f, 1.f, 0);
+        }
+        if (gr.dAdj) {
+            // dA += dU P^T   (P = X W recomputed)
+            transform(q, c, li, lv, io, params, l, Pj);
+            bgemm(q, dUj, Pj, gr.dAdj, nullptr, B, n, n, ct, ct, ct, n, (long)n * ct, (long)n * ct, (long)n * n, false,
+                  true, 1.f, 1.f, 0);
+        }
+    }
+}
+
+struct Scratch {
+    float *Pj, *Uj, *part, *logits;
+};
+
+// shared allocation walk for the forward (also used for sizing)
+Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
+    size_t maxPU = 0, maxPart = 0, maxLog = 0;
+    for (int j = 0; j <= c.num_pooling; ++j) {
+        const LevelInfo li = level_info(c, j);
+        const size_t rows = (size_t)c.B * li.n;
+        if (rows * li.cmax > maxPU) maxPU = rows * li.cmax;
+        if (rows * li.G * 2 > maxPart) maxPart = rows * li.G * 2;
+        if (li.a && rows * li.K > maxLog) maxLog = rows * li.K;
+    }
+    Scratch s{};
+    s.Pj = q.alloc<float>(maxPU);
+    s.Uj = q.alloc<float>(maxPU);
+    s.part = q.alloc<float>(maxPart);
+    s.logits = q.alloc<float>(maxLog > 0 ? maxLog : 1);
+    return s;
+}
+
+}  // namespace
+
+int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
+                    const float* assign_x, const int* num_nodes, float* ypred, float* assign_out, void* save) {
+    SaveLayout sv = layout_save(c, save);
+    Scratch sc = fwd_scratch(q, c);
+    if (q.err) return q.err;
+    const int B = c.B, P = c.num_pooling;
+    const int ldfeat = c.pred_dims[0];
+    int featoff = 0;
+    for (int j = 0; j <= P; ++j) {
+        const LevelInfo li = level_info(c, j);
+        const LevelSave& lv = sv.lv[j];
+        LevelIO io{};
+        io.x0e = j == 0 ? x : sv.lv[j - 1].Xn;
+        io.x0a = j == 0 ? assign_x : sv.lv[j - 1].Xn;
+        io.adj = j == 0 ? adj : sv.lv[j - 1].An;
+        level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part);
+        const int* nn_j = (j == 0) ? num_nodes : nullptr;
+        if (c.readout == 0) {
+            const int rw = readout_width(c, li);
+            const float* zsrc = (c.flags & DP_F_LAST_ONLY) ? lv.Ze + li.coff_e[li.L - 1] : lv.Ze;
+            masked_max_fwd(q, zsrc, li.D, c.mask_readout ? nn_j : nullptr, sv.feat + featoff, ldfeat, lv.argmax, rw, B,
+                           li.n, rw);
+            featoff += rw;
+        } else {
+            mask_rows(q, lv.Ze, li.D, sv.Zm, li.D, nn_j, B, li.n, li.D);
+            set2set_fwd(q, sv.Zm, li.D, PW(params, c.s2s_off[0]), PW(params, c.s2s_off[1]), PW(params, c.s2s_off[2]),
+                        PW(params, c.s2s_off[3]), PW(params, c.s2s_off[4]), PW(params, c.s2s_off[5]), sv.feat, B,
+                        li.n, li.D, sv.s2s);
+        }
+        if (j < P) {
+            const int K = li.K, n = li.n;
+            // S = softmax(Za Wp^T + bp) * mask
+            bgemm(q, lv.Za, PW(params, c.assign_pred_w_off[j]), sc.logits, PW(params, c.assign_pred_b_off[j]), B, n, K,
+                  li.Da, li.Da, li.Da, K, (long)n * li.Da, 0, (long)n * K, false, true, 1.f, 0.f, 0);
+            softmax_mask_fwd(q, sc.logits, K, lv.S, K, nn_j, B, n, K);
+            if (j == 0 && assign_out) q.copy(assign_out, lv.S, (size_t)B * n * K * sizeof(float));
+            // X' = S^T Z ; T = S^T A ; A' = T S
+            bgemm(q, lv.S, lv.Ze, lv.Xn, nullptr, B, K, li.D, n, K, li.D, li.D, (long)n * K, (long)n * li.D,
+                  (long)K * li.D, true, false, 1.f, 0.f, 0);
+            bgemm(q, lv.S, io.adj, lv.T, nullptr, B, K, n, n, K, n, n, (long)n * K, (long)n * n, (long)K * n, true, false,
+                  1.f, 0.f, 0);
+            bgemm(q, lv.T, lv.S, lv.An, nullptr, B, K, K, n, n, K, K, (long)K * n, (long)n * K, (long)K * K, false, false,
+                  1.f, 0.f, 0);
+        }
+    }
+    // pred_model
+    for (int i = 0; i < c.n_pred; ++i) {
+        const bool lastl = i == c.n_pred - 1;
+        float* out = lastl ? ypred : sv.hid[i + 1];
+        bgemm(q, sv.hid[i], PW(params, c.pred_w_off[i]), out, PW(params, c.pred_b_off[i]), 1, B, c.pred_dims[i + 1],
+              c.pred_dims[i], c.pred_dims[i], c.pred_dims[i], c.pred_dims[i + 1], 0, 0, 0, false, true, 1.f, 0.f,
+              lastl ? 0 : 1);
+    }
+    return q.err;
+}
+
+int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
+                     const float* assign_x, const int* num_nodes, const float* d_ypred, const float* d_assign,
+                     float* grads, const void* save) {
+    SaveLayout sv = layout_save(c, (void*)save);
+    const int B = c.B, P = c.num_pooling;
+    // ---- workspace walk
+    size_t maxPU = 0, maxPart = 0, maxSK = 0, maxMeans = 0;
+    LevelGrad gr[DP_MAX_LEVELS + 1]{};
+    for (int j = 0; j <= P; ++j) {
+        const LevelInfo li = level_info(c, j);
+        const size_t rows = (size_t)B * li.n;
+        if (rows * li.cmax > maxPU) maxPU = rows * li.cmax;
+        if (rows * li.G * 2 > maxPart) maxPart = rows * li.G * 2;
+        if ((size_t)li.n * li.G * 2 > maxMeans) maxMeans = (size_t)li.n * li.G * 2;
+        if (li.a && rows * li.K > maxSK) maxSK = rows * li.K;
+        gr[j].dZe = q.alloc<float>(rows * li.D);
+        gr[j].dZa = li.a ? q.alloc<float>(rows * li.Da) : nullptr;
+        gr[j].dX0 = j >= 1 ? q.alloc<float>(rows * li.e->dims[0]) : nullptr;
+        gr[j].dAdj = j >= 1 ? q.alloc<float>(rows * li.n) : nullptr;
+    }
+    float* Pj = q.alloc<float>(maxPU);
+    float* dUj = q.alloc<float>(maxPU);
+    float* Gj = q.alloc<float>(maxPU);
+    float* part = q.alloc<float>(maxPart);
+    float* means = q.alloc<float>(maxMeans);
+    float* dS = q.alloc<float>(maxSK ? maxSK : 1);
+    float* dlog = q.alloc<float>(maxSK ? maxSK : 1);
+    float* V = q.alloc<float>(maxSK ? maxSK : 1);
+    float* slabs = q.alloc<float>((size_t)B * (c.n_graph_params > 0 ? c.n_graph_params : 1));
+    float* dh[DP_MAX_PRED + 2];
+    for (int i = 0; i <= c.n_pred; ++i) dh[i] = q.alloc<float>((size_t)B * c.pred_dims[i]);
+    float* dZm = nullptr;
+    if (c.readout == 1) {
+        const LevelInfo li = level_info(c, 0);
+        dZm = q.alloc<float>((size_t)B * li.n * li.D);
+    }
+    if (q.err) return q.err;
+    const long slab_stride = c.n_graph_params;
+
+    q.zero(grads, (size_t)c.n_params * sizeof(float));
+    // ---- pred_model backward
+    q.copy(dh[c.n_pred], d_ypred, (size_t)B * c.pred_dims[c.n_pred] * sizeof(float));
+    for (int i = c.n_pred - 1; i >= 0; --i) {
+        const int din = c.pred_dims[i], dout = c.pred_dims[i + 1];
+        bgemm(q, dh[i + 1], sv.hid[i], grads + c.pred_w_off[i], nullptr, 1, dout, din, B, dout, din, din, 0, 0, 0, true,
+              false, 1.f, 0.f, 0);
+        if (c.pred_b_off[i] >= 0) colsum_batched(q, dh[i + 1], dout, 0, B, dout, grads + c.pred_b_off[i], 0, 1);
+        bgemm(q, dh[i + 1], PW(params, c.pred_w_off[i]), dh[i], nullptr, 1, B, din, dout, dout, din, din, 0, 0, 0, false,
+              false, 1.f, 0.f, 0);
+        if (i > 0) relu_bwd_inplace(q, dh[i], sv.hid[i], (long)B * din);
+    }
+    const float* dfeat = dh[0];
+    const int ldfeat = c.pred_dims[0];
+    // ---- readout backward -> dZe_j
+    int featoff = 0;
+    for (int j = 0; j <= P; ++j) {
+        const LevelInfo li = level_info(c, j);
+        q.zero(gr[j].dZe, (size_t)B * li.n * li.D * sizeof(float));
+        if (gr[j].dX0) q.zero(gr[j].dX0, (size_t)B * li.n * li.e->dims[0] * sizeof(float));
+        if (gr[j].dAdj) q.zero(gr[j].dAdj, (size_t)B * li.n * li.n * sizeof(float));
+        if (c.readout == 0) {
+            const int rw = readout_width(c, li);
+            float* dz = (c.flags & DP_F_LAST_ONLY) ? gr[j].dZe + li.coff_e[li.L - 1] : gr[j].dZe;
+            masked_max_bwd(q, dfeat + featoff, ldfeat, sv.lv[j].argmax, rw, dz, li.D, B, li.n, rw);
+            featoff += rw;
+        } else {
+            set2set_bwd(q, sv.Zm, li.D, PW(params, c.s2s_off[0]), PW(params, c.s2s_off[1]), PW(params, c.s2s_off[2]),
+                        PW(params, c.s2s_off[3]), PW(params, c.s2s_off[4]), PW(params, c.s2s_off[5]), sv.feat, dfeat,
+                        dZm, li.D, grads + c.s2s_off[0], grads + c.s2s_off[1], grads + c.s2s_off[2],
+                        grads + c.s2s_off[3], grads + c.s2s_off[4], grads + c.s2s_off[5], B, li.n, li.D, sv.s2s);
+            mask_rows(q, dZm, li.D, gr[j].dZe, li.D, num_nodes, B, li.n, li.D);
+        }
+    }
+    // ---- levels, top down
+    for (int j = P; j >= 0; --j) {
+        const LevelInfo li = level_info(c, j);
+        const LevelSave& lv = sv.lv[j];
+        LevelIO io{};
+        io.x0e = j == 0 ? x : sv.lv[j - 1].Xn;
+        io.x0a = j == 0 ? assign_x : sv.lv[j - 1].Xn;
+        io.adj = j == 0 ? adj : sv.lv[j - 1].An;
+        const int n = li.n;
+        if (j < P) {
+            const int K = li.K, D = li.D;
+            const float* dXn = gr[j + 1].dX0;
+            const float* dAn = gr[j + 1].dAdj;
+            // X' = S^T Z
+            bgemm(q, lv.S, dXn, gr[j].dZe, nullptr, B, n, D, K, K, D, D, (long)n * K, (long)K * D, (long)n * D, false,
+                  false, 1.f, 1.f, 0);
+            bgemm(q, lv.Ze, dXn, dS, nullptr, B, n, K, D, D, D, K, (long)n * D, (long)K * D, (long)n * K, false, true,
+                  1.f, 0.f, 0);
+            // A' = T S, T = S^T A
+            bgemm(q, lv.T, dAn, dS, nullptr, B, n, K, K, n, K, K, (long)K * n, (long)K * K, (long)n * K, true, false, 1.f,
+                  1.f, 0);
+            bgemm(q, lv.S, dAn, V, nullptr, B, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, true, 1.f,
+                  0.f, 0);
+            bgemm(q, io.adj, V, dS, nullptr, B, n, K, n, n, K, K, (long)n * n, (long)n * K, (long)n * K, false, false,
+                  1.f, 1.f, 0);
+            if (gr[j].dAdj) {
+                // dA_j += S dA' S^T
+                bgemm(q, lv.S, dAn, V, nullptr, B, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, false,
+                      1.f, 0.f, 0);
+                bgemm(q, V, lv.S, gr[j].dAdj, nullptr, B, n, n, K, K, K, n, (long)n * K, (long)n * K, (long)n * n, false,
+                      true, 1.f, 1.f, 0);
+            }
+            if (j == 0 && d_assign) axpy(q, dS, d_assign, 1.f, (long)B * n * K);
+            softmax_mask_bwd(q, lv.S, K, dS, K, j == 0 ? num_nodes : nullptr, dlog, K, B, n, K);
+            // assign_pred: logits = Za Wp^T + bp
+            bgemm(q, dlog, lv.Za, slabs + c.assign_pred_w_off[j], nullptr, B, K, li.Da, n, K, li.Da, li.Da, (long)n * K,
+                  (long)n * li.Da, slab_stride, true, false, 1.f, 0.f, 0);
+            if (c.assign_pred_b_off[j] >= 0)
+                colsum_batched(q, dlog, K, (long)n * K, n, K, slabs + c.assign_pred_b_off[j], slab_stride, B);
+            bgemm(q, dlog, PW(params, c.assign_pred_w_off[j]), gr[j].dZa, nullptr, B, n, li.Da, K, K, li.Da, li.Da,
+                  (long)n * K, 0, (long)n * li.Da, false, false, 1.f, 0.f, 0);
+        }
+        level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, Pj, dUj, Gj, part, means);
+    }
+    reduce_slabs(q, slabs, slab_stride, B, grads, c.n_graph_params, 0);
+    return q.err;
+}
+
+size_t encoder_save_bytes(const dp_encoder_cfg& c) { return layout_save(c, nullptr).total; }
+
+int encoder_validate(const dp_encoder_cfg* c) { return validate(c); }
+
+}  // namespace dp

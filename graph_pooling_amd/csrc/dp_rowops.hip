@@ -1,0 +1,568 @@
+// Row-wise / reduction kernels of the DiffPool path.  Rows here are short (20..276 floats),
+// so a row is handled by a 16-lane team (4 teams per wavefront): loads stay coalesced across
+// the consecutive rows of a wave and reductions are four xor-shuffles.
+#include "dp_common.h"
+
+namespace dp {
+
+#define L2_EPS 1e-12f
+#define BN_EPS 1e-5f
+
+__device__ inline float team_sum(float v) {
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    return v;
+}
+__device__ inline float team_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 8, 16));
+    v = fmaxf(v, __shfl_xor(v, 4, 16));
+    v = fmaxf(v, __shfl_xor(v, 2, 16));
+    v = fmaxf(v, __shfl_xor(v, 1, 16));
+    return v;
+}
+
+static inline int team_grid(long items) {
+    long blocks = (items + 15) / 16;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// ------------------------------------------------------------------ rownorm fwd
+// u = U[row, c0+c] (+ P[row, c0+c]) (+ bias[c]);  y = u / max(||u||, 1e-12)   (encoders.py:966-972)
+// optional BN partials of relu(y): (row mean, row M2) for a Chan-combine over the batch.
+struct RownormFwdArgs {
+    const float* U;
+    int ldu;
+    const float* P;
+    GroupCPtrs bias;
+    RowGroups g;
+    GroupPtrs yout;
+    float* invn;
+    float* part;
+    long rows;
+    int normalize, stats_mode;
+};
+
+__global__ __launch_bounds__(256) void k_rownorm_fwd(RownormFwdArgs a) {
+    const int tl = threadIdx.x & 15;
+    const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long nteams = (long)gridDim.x * 16;
+    const long items = a.rows * a.g.G;
+    for (long it = team; it < items; it += nteams) {
+        const long row = it / a.g.G;
+        const int g = (int)(it % a.g.G);
+        const int c0 = a.g.c0[g], w = a.g.w[g];
+        const float* u = a.U + row * a.ldu + c0;
+        const float* p = a.P ? a.P + row * a.ldu + c0 : nullptr;
+        const float* bias = a.bias.p[g];
+        float ss = 0.f;
+        for (int c = tl; c < w; c += 16) {
+            float v = u[c];
+            if (p) v += p[c];
+            if (bias) v += bias[c];
+            ss += v * v;
+        }
+        ss = team_sum(ss);
+        float inv = 1.f;
+        if (a.normalize) inv = 1.f / fmaxf(sqrtf(ss), L2_EPS);
+        float* y = a.yout.p[g] + row * a.yout.ld[g];
+        float s1 = 0.f;
+        for (int c = tl; c < w; c += 16) {
+            float v = u[c];
+            if (p) v += p[c];
+            if (bias) v += bias[c];
+            v *= inv;
+            y[c] = v;
+            s1 += a.stats_mode == 1 ? fmaxf(v, 0.f) : v;
+        }
+        if (tl == 0 && a.invn) a.invn[it] = inv;
+        if (a.stats_mode && a.part) {
+            s1 = team_sum(s1);
+            const float mean = s1 / (float)w;
+            float m2 = 0.f;
+            for (int c = tl; c < w; c += 16) {
+                float v = u[c];
+                if (p) v += p[c];
+                if (bias) v += bias[c];
+                v *= inv;
+                if (a.stats_mode == 1) v = fmaxf(v, 0.f);
+                v -= mean;
+                m2 += v * v;
+            }
+            m2 = team_sum(m2);
+            if (tl == 0) {
+                a.part[it * 2 + 0] = mean;
+                a.part[it * 2 + 1] = m2;
+            }
+        }
+    }
+}
+
+void rownorm_fwd(Seq& q, const float* U, int ldu, const float* P, GroupCPtrs bias, RowGroups g, GroupPtrs yout,
+                 float* invn, float* part, long rows, int normalize, int stats_mode) {
+    if (!q.ok() || rows <= 0) return;
+    RownormFwdArgs a{U, ldu, P, bias, g, yout, invn, part, rows, normalize, stats_mode};
+    hipLaunchKernelGGL(k_rownorm_fwd, dim3(team_grid(rows * g.G)), dim3(256), 0, q.stream, a);
+    q.check_launch("rownorm_fwd");
+}
+
+// ------------------------------------------------------------------ bn finalize
+// part[b, n, g, {mean, M2}] -> stats[n, g, {mu, rstd}]  (apply_bn, encoders.py:1048-1052:
+// per node index n, statistics over (batch, feature), biased variance, eps 1e-5).
+__global__ void k_bn_finalize(const float* part, float* stats, int B, int n, RowGroups g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * g.G) return;
+    const int node = i / g.G, gi = i % g.G;
+    const double w = (double)g.w[gi];
+    double sm = 0.0, sm2 = 0.0;
+    for (int b = 0; b < B; ++b) sm += (double)part[(((long)b * n + node) * g.G + gi) * 2];
+    const double mu = sm / (double)B;
+    for (int b = 0; b < B; ++b) {
+        const float* p = part + (((long)b * n + node) * g.G + gi) * 2;
+        const double d = (double)p[0] - mu;
+        sm2 += (double)p[1] + w * d * d;
+    }
+    const double var = sm2 / ((double)B * w);
+    stats[i * 2 + 0] = (float)mu;
+    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+}
+
+void bn_finalize(Seq& q, const float* part, float* stats, int B, int n, RowGroups g) {
+    if (!q.ok()) return;
+    const int items = n * g.G;
+    hipLaunchKernelGGL(k_bn_finalize, dim3((items + 255) / 256), dim3(256), 0, q.stream, part, stats, B, n, g);
+    q.check_launch("bn_finalize");
+}
+
+// part[b, n, g, {s0, s1}] -> means[n, g, {s0, s1}] / (B * w)   (BN backward reductions)
+__global__ void k_sum_finalize(const float* part, float* means, int B, int n, RowGroups g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * g.G) return;
+    const int node = i / g.G, gi = i % g.G;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* p = part + (((long)b * n + node) * g.G + gi) * 2;
+        s0 += (double)p[0];
+        s1 += (double)p[1];
+    }
+    const double cnt = (double)B * (double)g.w[gi];
+    means[i * 2 + 0] = (float)(s0 / cnt);
+    means[i * 2 + 1] = (float)(s1 / cnt);
+}
+
+void sum_finalize(Seq& q, const float* part, float* means, int B, int n, RowGroups g) {
+    if (!q.ok()) return;
+    const int items = n * g.G;
+    hipLaunchKernelGGL(k_sum_finalize, dim3((items + 255) / 256), dim3(256), 0, q.stream, part, means, B, n, g);
+    q.check_launch("sum_finalize");
+}
+
+// ------------------------------------------------------------------ bn apply fwd
+// x = (relu(y) - mu_n) * rstd_n  (or relu(y) when stats == null), written into the concat buffer.
+struct BnApplyArgs {
+    const float* Y;
+    int ldy;
+    const float* stats;
+    RowGroups g;
+    GroupPtrs xout;
+    long rows;
+    int n;
+    int relu;
+};
+__global__ __launch_bounds__(256) void k_bn_apply_fwd(BnApplyArgs a) {
+    const int tl = threadIdx.x & 15;
+    const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long nteams = (long)gridDim.x * 16;
+    const long items = a.rows * a.g.G;
+    for (long it = team; it < items; it += nteams) {
+        const long row = it / a.g.G;
+        const int g = (int)(it % a.g.G);
+        const int node = (int)(row % a.n);
+        float mu = 0.f, rstd = 1.f;
+        if (a.stats) {
+            mu = a.stats[((long)node * a.g.G + g) * 2];
+            rstd = a.stats[((long)node * a.g.G + g) * 2 + 1];
+        }
+        const float* y = a.Y + row * a.ldy + a.g.c0[g];
+        float* x = a.xout.p[g] + row * a.xout.ld[g];
+        for (int c = tl; c < a.g.w[g]; c += 16) {
+            const float v = a.relu ? fmaxf(y[c], 0.f) : y[c];
+            x[c] = (v - mu) * rstd;
+        }
+    }
+}
+void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* stats, RowGroups g, GroupPtrs xout, int B,
+                  int n, int relu) {
+    if (!q.ok()) return;
+    BnApplyArgs a{Y, ldy, stats, g, xout, (long)B * n, n, relu};
+    hipLaunchKernelGGL(k_bn_apply_fwd, dim3(team_grid(a.rows * g.G)), dim3(256), 0, q.stream, a);
+    q.check_launch("bn_apply_fwd");
+}
+
+// ------------------------------------------------------------------ bn bwd partials
+// per (row, group): sum_f dx, sum_f dx * xhat
+struct BnBwdPartArgs {
+    GroupCPtrs dx, xhat;
+    RowGroups g;
+    float* part;
+    long rows;
+};
+__global__ __launch_bounds__(256) void k_bn_bwd_partials(BnBwdPartArgs a) {
+    const int tl = threadIdx.x & 15;
+    const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long nteams = (long)gridDim.x * 16;
+    const long items = a.rows * a.g.G;
+    for (long it = team; it < items; it += nteams) {
+        const long row = it / a.g.G;
+        const int g = (int)(it % a.g.G);
+        const float* dx = a.dx.p[g] + row * a.dx.ld[g];
+        const float* xh = a.xhat.p[g] + row * a.xhat.ld[g];
+        float s0 = 0.f, s1 = 0.f;
+        for (int c = tl; c < a.g.w[g]; c += 16) {
+            const float d = dx[c];
+            s0 += d;
+            s1 += d * xh[c];
+        }
+        s0 = team_sum(s0);
+        s1 = team_sum(s1);
+        if (tl == 0) {
+            a.part[it * 2] = s0;
+            a.part[it * 2 + 1] = s1;
+        }
+    }
+}
+void bn_bwd_partials(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, RowGroups g, float* part, long rows) {
+    if (!q.ok()) return;
+    BnBwdPartArgs a{dx, xhat, g, part, rows};
+    hipLaunchKernelGGL(k_bn_bwd_partials, dim3(team_grid(rows * g.G)), dim3(256), 0, q.stream, a);
+    q.check_launch("bn_bwd_partials");
+}
+
+// ------------------------------------------------------------------ rownorm bwd
+// dx -> (BN bwd) -> (ReLU bwd) -> (l2-normalise bwd) -> dU
+//   dR = rstd * (dx - m0 - xhat * m1);  dY = dR * (y > 0)
+//   dU = inv * (dY - y * <y, dY>)   when ||u|| >= eps, else inv * dY  (clamp_min branch of F.normalize)
+struct RownormBwdArgs {
+    GroupCPtrs dx, xhat, y;
+    const float* invn;
+    const float* stats;
+    const float* means;
+    RowGroups g;
+    float* dU;
+    int ldu;
+    long rows;
+    int n;
+    int has_relu, has_bn, normalize;
+};
+__global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
+    const int tl = threadIdx.x & 15;
+    const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long nteams = (long)gridDim.x * 16;
+    const long items = a.rows * a.g.G;
+    for (long it = team; it < items; it += nteams) {
+        const long row = it / a.g.G;
+        const int g = (int)(it % a.g.G);
+        const int node = (int)(row % a.n);
+        const int w = a.g.w[g];
+        const float* dx = a.dx.p[g] + row * a.dx.ld[g];
+        const float* y = a.y.p[g] + row * a.y.ld[g];
+        const float* xh = a.has_bn ? a.xhat.p[g] + row * a.xhat.ld[g] : nullptr;
+        float rstd = 1.f, m0 = 0.f, m1 = 0.f;
+        if (a.has_bn) {
+            rstd = a.stats[((long)node * a.g.G + g) * 2 + 1];
+            m0 = a.means[((long)node * a.g.G + g) * 2];
+            m1 = a.means[((long)node * a.g.G + g) * 2 + 1];
+        }
+        const float inv = a.normalize ? a.invn[it] : 1.f;
+        const bool project = a.normalize && (inv < 1.0f / L2_EPS);
+        float dot = 0.f;
+        for (int c = tl; c < w; c += 16) {
+            float d = dx[c];
+            const float yy = y[c];
+            if (a.has_bn) d = rstd * (d - m0 - xh[c] * m1);
+            if (a.has_relu) d = yy > 0.f ? d : 0.f;
+            dot += d * yy;
+        }
+        dot = team_sum(dot);
+        float* du = a.dU + row * a.ldu + a.g.c0[g];
+        for (int c = tl; c < w; c += 16) {
+            float d = dx[c];
+            const float yy = y[c];
+            if (a.has_bn) d = rstd * (d - m0 - xh[c] * m1);
+            if (a.has_relu) d = yy > 0.f ? d : 0.f;
+            du[c] = project ? inv * (d - yy * dot) : inv * d;
+        }
+    }
+}
+void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const float* invn, const float* stats,
+                 const float* means, RowGroups g, float* dU, int ldu, int B, int n, int has_relu, int has_bn,
+                 int normalize) {
+    if (!q.ok()) return;
+    RownormBwdArgs a{dx, xhat, y, invn, stats, means, g, dU, ldu, (long)B * n, n, has_relu, has_bn, normalize};
+    hipLaunchKernelGGL(k_rownorm_bwd, dim3(team_grid(a.rows * g.G)), dim3(256), 0, q.stream, a);
+    q.check_launch("rownorm_bwd");
+}
+
+// ------------------------------------------------------------------ column sums
+// out[b, c] = sum_r X[b, r, c]    (bias gradients; deterministic)
+__global__ __launch_bounds__(256) void k_colsum_batched(const float* X, int ldx, long strideX, int rows, int cols,
+                                                        float* out, long strideOut) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < cols) {
+        const float* x = X + (long)b * strideX + c;
+        for (int r = rl; r < rows; r += 4) s += x[(long)r * ldx];
+    }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) out[(long)b * strideOut + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+void colsum_batched(Seq& q, const float* X, int ldx, long strideX, int rows, int cols, float* out, long strideOut,
+                    int batch) {
+    if (!q.ok() || cols <= 0 || batch <= 0) return;
+    hipLaunchKernelGGL(k_colsum_batched, dim3((cols + 63) / 64, batch), dim3(256), 0, q.stream, X, ldx, strideX,
+                       rows, cols, out, strideOut);
+    q.check_launch("colsum_batched");
+}
+
+// ------------------------------------------------------------------ softmax * mask
+// S = softmax_K(logits) for n < num_nodes[b], 0 otherwise  (encoders.py:1273-1275)
+__global__ __launch_bounds__(256) void k_softmax_mask_fwd(const float* logits, int ldl, float* S, int lds,
+                                                          const int* num_nodes, long rows, int n, int K) {
+    const int tl = threadIdx.x & 15;
+    const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long nteams = (long)gridDim.x * 16;
+    for (long row = team; row < rows; row += nteams) {
+        const int b = (int)(row / n), node = (int)(row % n);
+        const bool valid = num_nodes ? node < num_nodes[b] : true;
+        const float* l = logits + row * ldl;
+        float* s = S + row * lds;
+        if (!valid) {
+            for (int c = tl; c < K; c += 16) s[c] = 0.f;
+            continue;
+        }
+        float m = -INFINITY;
+        for (int c = tl; c < K; c += 16) m = fmaxf(m, l[c]);
+        m = team_max(m);
+        float sum = 0.f;
+        for (int c = tl; c < K; c += 16) sum += expf(l[c] - m);
+        sum = team_sum(sum);
+        const float r = 1.f / sum;
+        for (int c = tl; c < K; c += 16) s[c] = expf(l[c] - m) * r;
+    }
+}
+void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, const int* num_nodes, int B, int n,
+                      int K) {
+    if (!q.ok()) return;
+    const long rows = (long)B * n;
+    hipLaunchKernelGGL(k_softmax_mask_fwd, dim3(team_grid(rows)), dim3(256), 0, q.stream, logits, ldl, S, lds,
+                       num_nodes, rows, n, K);
+    q.check_launch("softmax_mask_fwd");
+}
+
+// dlogits = S * (dS - <dS, S>)   (rows with n >= num_nodes: S = 0 -> dlogits = 0)
+__global__ __launch_bounds__(256) void k_softmax_mask_bwd(const float* S, int lds, const float* dS, int ldds,
+                                                          const int* num_nodes, float* dl, int ldl, long rows, int n,
+                                                          int K) {
+    const int tl = threadIdx.x & 15;
+    const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long nteams = (long)gridDim.x * 16;
+    for (long row = team; row < rows; row += nteams) {
+        const float* s = S + row * lds;
+        const float* d = dS + row * ldds;
+        float dot = 0.f;
+        for (int c = tl; c < K; c += 16) dot += s[c] * d[c];
+        dot = team_sum(dot);
+        float* o = dl + row * ldl;
+        for (int c = tl; c < K; c += 16) o[c] = s[c] * (d[c] - dot);
+    }
+}
+void softmax_mask_bwd(Seq& q, const float* S, int lds, const float* dS, int ldds, const int* num_nodes,
+                      float* dlogits, int ldl, int B, int n, int K) {
+    if (!q.ok()) return;
+    const long rows = (long)B * n;
+    hipLaunchKernelGGL(k_softmax_mask_bwd, dim3(team_grid(rows)), dim3(256), 0, q.stream, S, lds, dS, ldds,
+                       num_nodes, dlogits, ldl, rows, n, K);
+    q.check_launch("softmax_mask_bwd");
+}
+
+// ------------------------------------------------------------------ masked max readout
+// out[b, f] = max_n (n < n_b ? Z[b, n, f] : 0)   (max over Z * mask, encoders.py:1079-1080,1257).
+// Ties -> lowest row index (torch CPU max).  argmax = -1 when the winner is a masked (zero) row.
+__global__ __launch_bounds__(256) void k_masked_max_fwd(const float* Z, int ldz, const int* num_nodes, float* out,
+                                                        int ldo, int* argmax, int lda, int n, int F) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int b = blockIdx.y;
+    const int fl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + fl;
+    const int nb = num_nodes ? min(num_nodes[b], n) : n;
+    float best = -INFINITY;
+    int bi = -1;
+    if (f < F) {
+        const float* z = Z + (long)b * n * ldz + f;
+        for (int r = rl; r < nb; r += 4) {
+            const float v = z[(long)r * ldz];
+            if (v > best) {
+                best = v;
+                bi = r;
+            }
+        }
+    }
+    sv[rl][fl] = best;
+    si[rl][fl] = bi;
+    __syncthreads();
+    if (rl == 0 && f < F) {
+        for (int k = 1; k < 4; ++k) {
+            const float v = sv[k][fl];
+            const int i = si[k][fl];
+            if (i >= 0 && (v > best || (v == best && i < bi))) {
+                best = v;
+                bi = i;
+            }
+        }
+        if (nb < n && !(best > 0.f)) {   // a masked zero row wins; it precedes no valid row only if 0 > best,
+            if (best < 0.f || bi < 0) {  // on an exact tie (best == 0) the valid row has the lower index
+                best = 0.f;
+                bi = -1;
+            }
+        }
+        out[(long)b * ldo + f] = best;
+        argmax[(long)b * lda + f] = bi;
+    }
+}
+void masked_max_fwd(Seq& q, const float* Z, int ldz, const int* num_nodes, float* out, int ldo, int* argmax,
+                    int lda, int B, int n, int F) {
+    if (!q.ok()) return;
+    hipLaunchKernelGGL(k_masked_max_fwd, dim3((F + 63) / 64, B), dim3(256), 0, q.stream, Z, ldz, num_nodes, out,
+                       ldo, argmax, lda, n, F);
+    q.check_launch("masked_max_fwd");
+}
+
+__global__ void k_masked_max_bwd(const float* dout, int ldo, const int* argmax, int lda, float* dZ, int ldz, int B,
+                                 int n, int F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * F) return;
+    const int b = i / F, f = i % F;
+    const int r = argmax[(long)b * lda + f];
+    if (r >= 0) dZ[((long)b * n + r) * ldz + f] += dout[(long)b * ldo + f];
+}
+void masked_max_bwd(Seq& q, const float* dout, int ldo, const int* argmax, int lda, float* dZ, int ldz, int B,
+                    int n, int F) {
+    if (!q.ok()) return;
+    hipLaunchKernelGGL(k_masked_max_bwd, dim3((B * F + 255) / 256), dim3(256), 0, q.stream, dout, ldo, argmax, lda,
+                       dZ, ldz, B, n, F);
+    q.check_launch("masked_max_bwd");
+}
+
+// dst[b, r, :] = r < num_nodes[b] ? src[b, r, :] : 0     (x_tensor * embedding_mask, encoders.py:1079-1080)
+__global__ void k_mask_rows(const float* src, int lds, float* dst, int ldd, const int* num_nodes, int B, int n,
+                            int F) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)B * n * F;
+    if (i >= total) return;
+    const int f = (int)(i % F);
+    const long row = i / F;
+    const int b = (int)(row / n), r = (int)(row % n);
+    const bool valid = num_nodes ? r < num_nodes[b] : true;
+    dst[row * ldd + f] = valid ? src[row * lds + f] : 0.f;
+}
+void mask_rows(Seq& q, const float* src, int lds, float* dst, int ldd, const int* num_nodes, int B, int n, int F) {
+    if (!q.ok()) return;
+    const long total = (long)B * n * F;
+    hipLaunchKernelGGL(k_mask_rows, dim3((total + 255) / 256), dim3(256), 0, q.stream, src, lds, dst, ldd, num_nodes,
+                       B, n, F);
+    q.check_launch("mask_rows");
+}
+
+// ------------------------------------------------------------------ small elementwise
+__global__ void k_relu_bwd(float* d, const float* h, long count) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && !(h[i] > 0.f)) d[i] = 0.f;
+}
+void relu_bwd_inplace(Seq& q, float* d, const float* h, long count) {
+    if (!q.ok() || count <= 0) return;
+    hipLaunchKernelGGL(k_relu_bwd, dim3((count + 255) / 256), dim3(256), 0, q.stream, d, h, count);
+    q.check_launch("relu_bwd");
+}
+
+__global__ void k_axpy(float* y, const float* x, float a, long count) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) y[i] += a * x[i];
+}
+void axpy(Seq& q, float* y, const float* x, float a, long count) {
+    if (!q.ok() || count <= 0) return;
+    hipLaunchKernelGGL(k_axpy, dim3((count + 255) / 256), dim3(256), 0, q.stream, y, x, a, count);
+    q.check_launch("axpy");
+}
+
+// ------------------------------------------------------------------ cross entropy
+// loss = mean_b (logsumexp(logits_b) - logits_b[label_b])   (F.cross_entropy, encoders.py:1127)
+__global__ __launch_bounds__(256) void k_ce_fwd(const float* logits, const long long* label, float* loss,
+                                                float* prob, int B, int C) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* l = logits + (long)b * C;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, l[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(l[c] - m);
+        const float lse = m + logf(s);
+        const long long y = label[b];
+        acc += lse - l[y];
+        if (prob)
+            for (int c = 0; c < C; ++c) prob[(long)b * C + c] = expf(l[c] - lse);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] / (float)B;
+}
+void ce_fwd(Seq& q, const float* logits, const long long* label, float* loss, float* prob, int B, int C) {
+    if (!q.ok()) return;
+    hipLaunchKernelGGL(k_ce_fwd, dim3(1), dim3(256), 0, q.stream, logits, label, loss, prob, B, C);
+    q.check_launch("ce_fwd");
+}
+__global__ void k_ce_bwd(const float* prob, const long long* label, const float* dloss, float scale, float* dl,
+                         int B, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    const float g = (dloss ? dloss[0] : 1.f) * scale / (float)B;
+    dl[i] = g * (prob[i] - (label[b] == c ? 1.f : 0.f));
+}
+void ce_bwd(Seq& q, const float* prob, const long long* label, const float* dloss, float scale, float* dlogits,
+            int B, int C) {
+    if (!q.ok()) return;
+    hipLaunchKernelGGL(k_ce_bwd, dim3((B * C + 255) / 256), dim3(256), 0, q.stream, prob, label, dloss, scale,
+                       dlogits, B, C);
+    q.check_launch("ce_bwd");
+}
+
+// ------------------------------------------------------------------ slab reduce
+// out[p] (+)= sum_b slabs[b, p]   — per-graph parameter-gradient slabs -> the flat gradient buffer
+__global__ void k_reduce_slabs(const float* slabs, long stride, int B, float* out, long count, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += slabs[(long)b * stride + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, long count, int accumulate) {
+    if (!q.ok() || count <= 0) return;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((count + 255) / 256), dim3(256), 0, q.stream, slabs, stride, B, out,
+                       count, accumulate);
+    q.check_launch("reduce_slabs");
+}
+
+}  // namespace dp

@@ -1,0 +1,93 @@
+"""Data parallelism over graphs: one process per GPU, one RCCL all-reduce per step.
+
+Every contraction of the DiffPool path is per graph, so a batch shards over ranks with exactly one
+exchange per step: the sum of the flat fp32 gradient buffer (42 KB ENZYMES / 75 KB DD / <= 1 MB ER —
+SURVEY.md §8(e)).  That is latency-bound, far below the xGMI link rate, so the whole model is ONE
+bucket and ONE collective (`torch.distributed` backend "nccl" = RCCL on ROCm; "gloo" on CPU for tests);
+there is nothing to overlap it with.  The reference has no distributed code at all (train.py:624 picks
+a single device).
+
+BatchNorm caveat: apply_bn normalises per node index over the LOCAL batch
+(encoders.py:1048-1052), so a sharded step equals "world_size independent reference steps with
+averaged gradients", not one step on the concatenated batch.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallelEncoder:
+    """Wraps one of the encoders of graph_pooling_amd.encoders.
+
+        dp = DataParallelEncoder(model)        # after model.cuda(); broadcasts rank 0's parameters
+        loss.backward(); dp.reduce_gradients(); clip_grad_norm_(...); optimizer.step()
+    """
+
+    def __init__(self, model, process_group: Optional[dist.ProcessGroup] = None, broadcast: bool = True):
+        self.model = model
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        device = next(model.parameters()).device
+        model._ensure_flat(device)
+        if broadcast and self.world > 1:
+            self.sync_parameters()
+
+    def __getattr__(self, name):
+        return getattr(self.model, name)
+
+    def __call__(self, *a, **k):
+        return self.model(*a, **k)
+
+    def sync_parameters(self, src: int = 0):
+        """Every rank starts from rank `src`'s flat parameter buffer (one broadcast)."""
+        m = self.model
+        m._ensure_flat(next(m.parameters()).device)
+        dist.broadcast(m._flat, src=src, group=self.group)
+
+    def _aliased_flat_grad(self):
+        m = self.model
+        g = getattr(m, "_last_flat_grad", None)
+        if g is None:
+            return None
+        base = g.data_ptr()
+        for p, (off, numel, _) in zip(m._flat_params, m._flat_index):
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                return None
+        return g
+
+    def reduce_gradients(self):
+        """Average gradients over ranks with ONE all-reduce of the flat buffer."""
+        if self.world == 1:
+            return
+        m = self.model
+        flat = self._aliased_flat_grad()
+        if flat is not None:
+            # the autograd engine kept our views: p.grad already aliases the flat buffer
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world)
+            return
+        device = m._flat.device
+        flat = torch.zeros(m._flat.numel(), device=device, dtype=torch.float32)
+        for p, (off, numel, _) in zip(m._flat_params, m._flat_index):
+            if p.grad is not None:
+                flat[off:off + numel].copy_(p.grad.reshape(-1))
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.div_(self.world)
+        for p, (off, numel, shape) in zip(m._flat_params, m._flat_index):
+            if p.grad is None:
+                p.grad = flat[off:off + numel].view(shape)
+            else:
+                p.grad.copy_(flat[off:off + numel].view(shape))
+
+
+def shard_batch(batch: dict, rank: int, world: int) -> dict:
+    """Contiguous, equal shards of a collated batch dict (adj / feats / num_nodes / label / assign_feats)."""
+    B = len(batch["num_nodes"])
+    if B % world != 0:
+        raise ValueError(f"batch size {B} is not divisible by world size {world}")
+    per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    return {k: v[sl] for k, v in batch.items()}

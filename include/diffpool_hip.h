@@ -1,0 +1,239 @@
+/* diffpool_hip.h — C ABI of libdiffpool_hip.so (MI355X / gfx950).
+ *
+ * The reference (JiaxuanYou/graph-pooling) has no FFI of its own: its DiffPool path is stock
+ * torch calls inside encoders.py / set2set.py / aggregators.py.  Each entry point below replaces
+ * the torch call sites named in its comment (file:line relative to the reference root); the
+ * Python modules in graph_pooling_amd/ bind them with ctypes.
+ *
+ * Conventions
+ *   - every tensor is fp32, row-major; `ld*` is a row stride in ELEMENTS; batch-major [B, n, ·]
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
+ *     buffer including the workspace; the library never allocates, frees or retains memory
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises the
+ *     device, so every entry point can be captured into a hipGraph
+ *   - return value: 0 = ok; < 0 = argument / workspace error detected before any launch
+ *     (DP_ERR_*); > 0 = the hipError_t of a failed launch.  dp_last_error_string() describes the
+ *     last failure of the calling thread.  No C++ exception crosses this boundary.
+ *   - `num_nodes` is int32[B] on the device (it replaces the host-built mask of
+ *     construct_mask, encoders.py:1035-1046); NULL means "no masking"
+ */
+#ifndef DIFFPOOL_HIP_H
+#define DIFFPOOL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden */
+#endif
+
+#define DP_VERSION 100 /* 0.1.0 */
+
+#define DP_OK 0
+#define DP_ERR_INVALID_ARG (-1)
+#define DP_ERR_WORKSPACE (-2)
+#define DP_ERR_UNSUPPORTED (-3)
+
+/* layer flags */
+#define DP_F_ADD_SELF 1   /* y += x before the weight (GraphConv add_self, encoders.py:966-967) */
+#define DP_F_NORMALIZE 2  /* F.normalize(p=2, dim=2), encoders.py:971-972 */
+#define DP_F_RELU 4
+#define DP_F_BN 8         /* apply_bn after ReLU, encoders.py:1062-1064 */
+#define DP_F_LAST_ONLY 16 /* readout of the last layer only (concat=False, encoders.py:1118-1119) */
+
+#define DP_MAX_LAYERS 8
+#define DP_MAX_LEVELS 4   /* pooling levels */
+#define DP_MAX_PRED 4     /* hidden layers of pred_model */
+
+int dp_version(void);
+const char* dp_last_error_string(void);
+
+/* ------------------------------------------------------------------ generic contraction
+ * C[b] = act(alpha * op(A[b]) op(B[b]) + beta * C[b] + bias), fp32 MFMA (exact f32).
+ * Replaces torch.matmul / @ at encoders.py:965,968,1278,1279,1311.  act: 0 none, 1 relu. */
+int dp_bgemm_f32(const float* A, const float* B, float* C, const float* bias, int batch, int M, int N,
+                 int K, int lda, int ldb, int ldc, long strideA, long strideB, long strideC, int transA,
+                 int transB, float alpha, float beta, int act, void* stream);
+
+/* ------------------------------------------------------------------ A1  GraphConv
+ * y = l2norm((adj @ x [+ x]) @ W + b)   — GraphConv.forward, encoders.py:962-974.
+ * x [B,n,Fin] (ldx), adj [B,n,n], W [Fin,Fout], bias [Fout] or NULL, y [B,n,Fout] (ldy),
+ * invnorm [B,n] (saved for backward, may be NULL).  flags: DP_F_ADD_SELF | DP_F_NORMALIZE.
+ * Workspace: dp_gcn_layer_workspace_bytes(). */
+size_t dp_gcn_layer_workspace_bytes(int B, int n, int Fin, int Fout);
+int dp_gcn_layer_fwd(const float* x, int ldx, const float* adj, const float* W, const float* bias,
+                     float* y, int ldy, float* invnorm, int B, int n, int Fin, int Fout, int flags,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of the above. dx / dadj may be NULL (not needed). dW [Fin,Fout] and db [Fout] are
+ * OVERWRITTEN. */
+int dp_gcn_layer_bwd(const float* x, int ldx, const float* adj, const float* W, const float* y, int ldy,
+                     const float* invnorm, const float* dy, int lddy, float* dx, int lddx, float* dW,
+                     float* db, float* dadj, int B, int n, int Fin, int Fout, int flags, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ A3  apply_bn
+ * Batch-norm over the node index with batch statistics (a fresh BatchNorm1d(n) per call,
+ * encoders.py:1048-1052): per node n, mean / biased variance over (batch, feature), eps 1e-5.
+ * stats [n,2] receives (mean, rstd).  relu != 0 applies ReLU first (encoders.py:1062). */
+size_t dp_bn_node_workspace_bytes(int B, int n, int F);
+int dp_bn_node_fwd(const float* x, int ldx, float* y, int ldy, float* stats, int B, int n, int F,
+                   int relu, void* workspace, size_t workspace_bytes, void* stream);
+/* dx from dy; y is the forward OUTPUT (xhat), x the forward input (used for the ReLU mask when
+ * relu != 0, may be NULL otherwise). */
+int dp_bn_node_bwd(const float* x, int ldx, const float* y, int ldy, const float* stats, const float* dy,
+                   int lddy, float* dx, int lddx, int B, int n, int F, int relu, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ A5  assignment head
+ * S = softmax_K(z @ Wp^T + bp) * mask — encoders.py:1273-1275. z [B,n,Din] (ldz), Wp [K,Din]
+ * (nn.Linear layout), S [B,n,K]. */
+size_t dp_assign_workspace_bytes(int B, int n, int Din, int K);
+int dp_assign_softmax_mask_fwd(const float* z, int ldz, const float* Wp, const float* bp,
+                               const int* num_nodes, float* S, int B, int n, int Din, int K,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int dp_assign_softmax_mask_bwd(const float* z, int ldz, const float* Wp, const float* S, const float* dS,
+                               const int* num_nodes, float* dz, int lddz, float* dWp, float* dbp, int B,
+                               int n, int Din, int K, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
+/* ------------------------------------------------------------------ A6  pooling
+ * Xp = S^T Z [B,K,D], Ap = S^T A S [B,K,K] — encoders.py:1278-1279.
+ * T [B,K,n] receives S^T A (saved for backward). */
+int dp_pool_fwd(const float* S, const float* Z, int ldz, const float* adj, float* Xp, float* Ap, float* T,
+                int B, int n, int K, int D, void* stream);
+/* dS [B,n,K] (overwritten), dZ [B,n,D] (lddz; ACCUMULATED INTO), dadj [B,n,n] or NULL
+ * (accumulated into). */
+size_t dp_pool_bwd_workspace_bytes(int B, int n, int K, int D);
+int dp_pool_bwd(const float* S, const float* Z, int ldz, const float* adj, const float* T, const float* dXp,
+                const float* dAp, float* dS, float* dZ, int lddz, float* dadj, int B, int n, int K, int D,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ A7  max readout
+ * out[b,f] = max_n (Z * mask)[b,n,f] — encoders.py:1079-1080,1257,1287.  argmax [B,F] int32
+ * (-1 where a masked zero row wins: no gradient). */
+int dp_masked_max_fwd(const float* Z, int ldz, const int* num_nodes, float* out, int ldo, int* argmax,
+                      int B, int n, int F, void* stream);
+/* dZ is ACCUMULATED INTO. */
+int dp_masked_max_bwd(const float* dout, int ldo, const int* argmax, float* dZ, int lddz, int B, int n,
+                      int F, void* stream);
+
+/* ------------------------------------------------------------------ A8  link-prediction loss
+ * loss = sum_{n,m < n_b} [-A log(P+1e-7) - (1-A) log(1-P+1e-7)] / sum_b n_b^2,
+ * P = min(S S^T, 1) — encoders.py:1309-1331 (adj_hop = 1).  loss_out: 1 float. */
+size_t dp_linkpred_workspace_bytes(int B, int n, int K);
+int dp_linkpred_loss_fwd(const float* S, const float* adj, const int* num_nodes, float* loss_out, int B,
+                         int n, int K, void* workspace, size_t workspace_bytes, void* stream);
+/* dS (+)= dloss * d loss / dS.  dloss: device pointer to 1 float (NULL = 1.0). */
+int dp_linkpred_loss_bwd(const float* S, const float* adj, const int* num_nodes, const float* dloss,
+                         float* dS, int accumulate, int B, int n, int K, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ softmax cross entropy
+ * loss = mean_b CE(logits_b, label_b) — F.cross_entropy, encoders.py:1127.  prob [B,C] is saved
+ * for backward.  label: int64[B]. */
+int dp_cross_entropy_fwd(const float* logits, const long long* label, float* loss_out, float* prob, int B,
+                         int C, void* stream);
+int dp_cross_entropy_bwd(const float* prob, const long long* label, const float* dloss, float* dlogits,
+                         int B, int C, void* stream);
+
+/* ------------------------------------------------------------------ A10  Set2Set
+ * Set2Set.forward, set2set.py:32-57: n LSTM-attention steps over emb [B,n,d] -> out [B,d].
+ * Weights in nn.LSTM layout: w_ih [4d,2d], w_hh [4d,d], b_ih [4d], b_hh [4d] (gates i,f,g,o);
+ * pred: Wp [d,2d], bp [d].  `save` (dp_set2set_save_bytes) keeps per-step state for backward. */
+size_t dp_set2set_save_bytes(int B, int n, int d);
+int dp_set2set_fwd(const float* emb, int lde, const float* w_ih, const float* w_hh, const float* b_ih,
+                   const float* b_hh, const float* Wp, const float* bp, float* out, int B, int n, int d,
+                   void* save, size_t save_bytes, void* stream);
+size_t dp_set2set_bwd_workspace_bytes(int B, int n, int d);
+int dp_set2set_bwd(const float* emb, int lde, const float* w_ih, const float* w_hh, const float* b_ih,
+                   const float* b_hh, const float* Wp, const float* bp, const float* out, const float* dout,
+                   float* demb, int ldde, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dWp,
+                   float* dbp, int B, int n, int d, const void* save, size_t save_bytes, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ A9  mean aggregator
+ * out[i,:] = mean_{j in indices[indptr[i]:indptr[i+1]]} table[j,:] — MeanAggregator.forward with
+ * num_sample=None, aggregators.py:50-62 (the row-normalised mask times the embedding matrix, as a
+ * CSR gather-mean).  Rows with no neighbour give 0/0 = NaN in the reference; here too. */
+int dp_mean_aggregate_fwd(const float* table, int ldt, const int* indptr, const int* indices, float* out,
+                          int ldo, int n_rows, int feat, void* stream);
+/* dtable [n_table, feat] is ACCUMULATED INTO (atomic adds). */
+int dp_mean_aggregate_bwd(const float* dout, int ldo, const int* indptr, const int* indices, float* dtable,
+                          int ldt, int n_rows, int feat, void* stream);
+
+/* ================================================================== model-level entry points
+ * One call enqueues the whole forward (or backward) of an encoder, so the Python host pays one
+ * FFI crossing per pass instead of ~100.  Parameters live in ONE flat fp32 buffer; the cfg gives
+ * the offset (in floats) of every tensor.  Gradients are written to a flat buffer of the same
+ * layout (ready for a single RCCL all-reduce). */
+typedef struct {
+    int n_layers;                    /* L */
+    int dims[DP_MAX_LAYERS + 1];     /* dims[0] = input width, dims[l] = output width of layer l */
+    long w_off[DP_MAX_LAYERS];       /* weight [dims[l], dims[l+1]] offset in the flat buffer */
+    long b_off[DP_MAX_LAYERS];       /* bias [dims[l+1]] offset, or -1 */
+} dp_stack_cfg;
+
+typedef struct {
+    int B, N;                        /* batch, padded node count */
+    int num_pooling;                 /* P */
+    int n_nodes[DP_MAX_LEVELS + 1];  /* n_nodes[0] = N, n_nodes[j+1] = K_j (encoders.py:1203,1215) */
+    dp_stack_cfg embed[DP_MAX_LEVELS + 1]; /* embed[0]: conv_first/.. ; embed[j+1]: after pool j */
+    dp_stack_cfg assign[DP_MAX_LEVELS];    /* assign GCN of level j (input: assign_x / pooled X) */
+    long assign_pred_w_off[DP_MAX_LEVELS]; /* Linear [K_j, Da_j] (encoders.py:1210) */
+    long assign_pred_b_off[DP_MAX_LEVELS];
+    int n_pred;                      /* number of Linear layers in pred_model (hidden + 1) */
+    int pred_dims[DP_MAX_PRED + 2];  /* pred_dims[0] = D*(P+1) ... pred_dims[n_pred] = label_dim */
+    long pred_w_off[DP_MAX_PRED + 1];
+    long pred_b_off[DP_MAX_PRED + 1];
+    int flags;                       /* DP_F_BN | DP_F_ADD_SELF */
+    int readout;                     /* 0: max over nodes of the concat (DiffPool / base encoder),
+                                        1: Set2Set (GcnSet2SetEncoder) */
+    long s2s_off[6];                 /* w_ih, w_hh, b_ih, b_hh, pred.weight, pred.bias (readout 1) */
+    int mask_readout;                /* 1: level-0 embedding is masked before readout (DiffPool,
+                                        Set2Set encoder); 0: base encoder (encoders.py:1083-1122) */
+    long n_params;                   /* total floats in the flat buffer */
+    long n_graph_params;             /* params [0, n_graph_params) are the GCN stacks + assign heads
+                                        (their gradients are reduced from per-graph slabs); the
+                                        pred_model / Set2Set parameters follow */
+} dp_encoder_cfg;
+
+size_t dp_sizeof_encoder_cfg(void); /* sizeof(dp_encoder_cfg): lets a binding check its struct layout */
+size_t dp_encoder_save_bytes(const dp_encoder_cfg* cfg);
+size_t dp_encoder_workspace_bytes(const dp_encoder_cfg* cfg);
+
+/* SoftPoolingGcnEncoder.forward (encoders.py:1231-1300), GcnEncoderGraph.forward (:1083-1122,
+ * num_pooling = 0) and GcnSet2SetEncoder.forward (:1144-1157, readout = 1).
+ * x [B,N,F], adj [B,N,N], assign_x [B,N,Fa] (may alias x), num_nodes int32[B] or NULL.
+ * ypred [B,label_dim]; assign_out [B,N,K_0] (level-0 S, = assign_tensor when P = 1) or NULL when
+ * P = 0; `save` keeps activations for backward. */
+int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
+                       const float* assign_x, const int* num_nodes, float* ypred, float* assign_out,
+                       void* save, size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+/* d_ypred [B,label_dim]; d_assign [B,N,K_0] or NULL (gradient arriving at the level-0 assignment
+ * from the link-prediction loss); grads: flat, same layout as params, OVERWRITTEN. */
+int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
+                        const float* assign_x, const int* num_nodes, const float* d_ypred,
+                        const float* d_assign, float* grads, const void* save, size_t save_bytes,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* SoftPoolingGcnEncoder.loss (encoders.py:1302-1334): loss_out[0] = CE (+ link), loss_out[1] = link.
+ * prob [B,C] saved for backward.  S / adj may be NULL when linkpred == 0. */
+size_t dp_loss_workspace_bytes(int B, int N, int K, int linkpred);
+int dp_loss_forward(const float* ypred, const long long* label, const float* S, const float* adj,
+                    const int* num_nodes, float* loss_out, float* prob, int B, int C, int N, int K,
+                    int linkpred, void* workspace, size_t workspace_bytes, void* stream);
+/* dloss: device scalar (NULL = 1).  d_ypred [B,C], dS [B,N,K] (only when linkpred) overwritten. */
+int dp_loss_backward(const float* prob, const long long* label, const float* S, const float* adj,
+                     const int* num_nodes, const float* dloss, float* d_ypred, float* dS, int B, int C,
+                     int N, int K, int linkpred, void* workspace, size_t workspace_bytes, void* stream);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFPOOL_HIP_H */

@@ -1,0 +1,222 @@
+"""GPU parity of the nn.Module surface (graph_pooling_amd.encoders) against (a) the golden vectors the
+reference's own classes produced (tests/golden, oracle/make_golden.py) and (b) the CPU oracle on
+seeded synthetic batches up to BASELINE.json's DD shape.  The modules call libdiffpool_hip.so through
+the C ABI (dp_encoder_forward/backward, dp_loss_forward/backward).
+
+Tolerances (fp32 kernels, reduction-order differences only):
+  ypred / loss / assign: rtol 1e-4, atol 1e-5;   parameter gradients: rtol 2e-3, atol 2e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from graph_pooling_amd.encoders import GcnEncoderGraph, SoftPoolingGcnEncoder
+from oracle import diffpool_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+    b = b.detach().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(b)
+    torch.testing.assert_close(a.float(), b.float(), rtol=rtol, atol=atol)
+
+
+def grads_close(model, ref_grads, rtol=2e-3, atol=2e-5):
+    named = dict(model.named_parameters())
+    assert set(named) == set(ref_grads), set(named) ^ set(ref_grads)
+    for k, p in named.items():
+        assert p.grad is not None, k
+        g = ref_grads[k]
+        # scale atol with the gradient's magnitude so tiny-gradient tensors are still checked relatively
+        scale = float(g.abs().max())
+        close(p.grad, g, rtol=rtol, atol=max(atol, 2e-4 * scale))
+
+
+@pytest.mark.parametrize("name", ["g4_softpool_n16_f3", "g5_softpool_n16_f3_link", "g4_softpool_n100_f89",
+                                  "g5_softpool_n100_f89_link", "g9_enzymes_batch"])
+def test_softpool_against_reference_golden(name, golden):
+    a, params, grads = golden(name)
+    x = T(a["x"])
+    B, N, F_ = x.shape
+    if "adj" in a:
+        adj = T(a["adj"])
+    else:
+        adj = T(np.unpackbits(a["adj_bits"], axis=-1)[..., :N].astype(np.float32))
+    linkpred = "link_loss" in a
+    H = params["conv_first.weight"].shape[1]
+    E = params["conv_last.weight"].shape[1]
+    K = params["assign_pred.weight"].shape[0]
+    Cc = params["pred_model.2.weight"].shape[0]
+    model = SoftPoolingGcnEncoder(N, F_, H, E, Cc, 3, H, assign_ratio=K / N + 1e-9, linkpred=linkpred)
+    assert model.assign_dims == [K]
+    model.load_state_dict(params)            # same keys and shapes as the reference (Appendix D)
+    model = model.cuda()
+    xd, ad = x.cuda(), adj.cuda()
+    ypred = model(xd, ad, a["num_nodes"], assign_x=xd)
+    close(ypred, a["ypred"])
+    close(model.assign_tensor, a["assign"], 1e-4, 1e-6)
+    label = T(a["label"]).cuda()
+    loss = model.loss(ypred, label, ad, a["num_nodes"]) if linkpred else model.loss(ypred, label)
+    close(loss, a["loss"], 1e-5, 1e-6)
+    if linkpred:
+        close(model.link_loss, a["link_loss"], 1e-5, 1e-6)
+    loss.backward()
+    grads_close(model, grads)
+
+
+@pytest.mark.parametrize("tag", ["concat", "addself", "nobn"])
+def test_base_encoder_against_reference_golden(tag, golden):
+    a, params, grads = golden(f"g6_base_{tag}")
+    concat, bn, nh = [int(v) for v in a["cfg"]]
+    x, adj = T(a["x"]), T(a["adj"])
+    B, N, F_ = x.shape
+    H = params["conv_first.weight"].shape[1]
+    E = params["conv_last.weight"].shape[1]
+    hidden = [params["pred_model.0.weight"].shape[0]] if nh else []
+    Cc = params["pred_model.2.weight" if nh else "pred_model.weight"].shape[0]
+    model = GcnEncoderGraph(F_, H, E, Cc, 3, pred_hidden_dims=hidden, concat=bool(concat), bn=bool(bn))
+    model.load_state_dict(params)
+    model = model.cuda()
+    ypred = model(x.cuda(), adj.cuda(), a["num_nodes"])
+    close(ypred, a["ypred"])
+    loss = model.loss(ypred, T(a["label"]).cuda())
+    close(loss, a["loss"], 1e-5, 1e-6)
+    loss.backward()
+    grads_close(model, grads)
+
+
+def _oracle_run(params, x, adj, nn_, label, linkpred, num_pooling=1):
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    yo, inter = O.softpool_forward(P, x, adj, nn_, x, num_pooling=num_pooling)
+    lo, link = O.softpool_loss(yo, label, inter["assign_0"], adj, nn_, linkpred)
+    lo.backward()
+    return yo, inter, lo, {k: v.grad for k, v in P.items()}
+
+
+@pytest.mark.parametrize("B,N,F_,H,Cc,ratio,p,linkpred,tag", [
+    (20, 100, 3, 20, 6, 0.1, 0.10, True, "S-ENZ"),       # BASELINE configs[0] shape
+    (20, 500, 89, 20, 2, 0.1, 0.02, False, "S-DD"),      # BASELINE configs[1] shape (the metric's workload)
+    (20, 500, 89, 20, 2, 0.1, 0.02, True, "S-DD+link"),
+    (5, 67, 11, 12, 3, 0.25, 0.15, True, "odd"),
+])
+def test_softpool_against_oracle_synthetic(B, N, F_, H, Cc, ratio, p, linkpred, tag):
+    n_min = max(1, N // 10)
+    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=n_min, p=p, seed=1, n_classes=Cc)
+    model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, 3, H, assign_ratio=ratio, linkpred=linkpred)
+    params = O.init_params({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0, bias_scale=0.1)
+    model.load_state_dict(params)
+    model = model.cuda()
+    xd, ad = x.cuda(), adj.cuda()
+    ypred = model(xd, ad, nn_, assign_x=xd)
+    loss = model.loss(ypred, label.cuda(), ad, nn_) if linkpred else model.loss(ypred, label.cuda())
+    loss.backward()
+    yo, inter, lo, go = _oracle_run(params, x, adj, nn_, label, linkpred)
+    close(ypred, yo)
+    close(model.assign_tensor, inter["assign_0"], 1e-4, 1e-6)
+    close(loss, lo, 1e-4, 1e-6)
+    grads_close(model, go)
+
+
+def test_unmasked_batch_and_full_graphs():
+    # batch_num_nodes = None (no masking anywhere) and n_b == N for every graph
+    B, N, F_, H, Cc = 3, 24, 4, 8, 2
+    x, adj, _, label = O.make_batch(B, N, F_, n_min=N, p=0.2, seed=3, n_classes=Cc, onehot=False)
+    model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, 3, H, assign_ratio=0.25, linkpred=True)
+    params = O.init_params({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=4, bias_scale=0.1)
+    model.load_state_dict(params)
+    model = model.cuda()
+    ypred = model(x.cuda(), adj.cuda(), None, assign_x=x.cuda())
+    loss = model.loss(ypred, label.cuda(), adj.cuda(), None)
+    loss.backward()
+    yo, inter, lo, go = _oracle_run(params, x, adj, None, label, True)
+    close(ypred, yo)
+    close(loss, lo, 1e-4, 1e-6)
+    grads_close(model, go)
+
+
+def test_multi_pool_against_oracle_PARITY_UNPINNED():
+    """num_pooling = 2: the reference cannot execute this, so this is pinned
+    only against the build's own CPU restatement of the chosen semantics."""
+    B, N, F_, H, Cc = 4, 64, 6, 10, 3
+    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=8, p=0.1, seed=5, n_classes=Cc)
+    model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, 3, H, assign_ratio=0.25, num_pooling=2, linkpred=True)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    mine = O.softpool_param_shapes(max_num_nodes=N, input_dim=F_, hidden_dim=H, embedding_dim=H, label_dim=Cc,
+                                   num_layers=3, assign_hidden_dim=H, assign_ratio=0.25, num_pooling=2)
+    assert mine == shapes
+    params = O.init_params(shapes, seed=6, bias_scale=0.1)
+    model.load_state_dict(params)
+    model = model.cuda()
+    ypred = model(x.cuda(), adj.cuda(), nn_, assign_x=x.cuda())
+    loss = model.loss(ypred, label.cuda(), adj.cuda(), nn_)
+    loss.backward()
+    yo, inter, lo, go = _oracle_run(params, x, adj, nn_, label, True, num_pooling=2)
+    close(ypred, yo)
+    close(loss, lo, 1e-4, 1e-6)
+    grads_close(model, go)
+
+
+def test_adam_two_steps_golden(golden):
+    """train.py:173,209-210 — Adam(lr 1e-3) + clip_grad_norm(2.0) on top of the HIP fwd/bwd."""
+    a, params, _ = golden("g10_adam_two_steps")
+    x, adj = T(a["x"]).cuda(), T(a["adj"]).cuda()
+    label = T(a["label"]).cuda()
+    B, N, F_ = x.shape
+    model = SoftPoolingGcnEncoder(N, F_, 8, 8, 6, 3, 8, assign_ratio=0.25, linkpred=True)
+    model.load_state_dict(params)
+    model = model.cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=0.001)
+    for step in range(2):
+        model.zero_grad()
+        ypred = model(x, adj, a["num_nodes"], assign_x=x)
+        loss = model.loss(ypred, label, adj, a["num_nodes"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 2.0)
+        opt.step()
+        close(loss, a["losses"][step], 1e-5, 1e-6)
+    sd = model.state_dict()
+    for k, v in a["after"].items():
+        close(sd[k], v, 1e-4, 1e-6)
+
+
+def test_eval_mode_and_no_grad_match_train_forward():
+    # apply_bn always uses batch statistics, .eval() changes nothing
+    B, N, F_, H, Cc = 4, 32, 5, 8, 3
+    x, adj, nn_, _ = O.make_batch(B, N, F_, n_min=3, p=0.2, seed=7, n_classes=Cc)
+    model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, 3, H, assign_ratio=0.25, linkpred=False).cuda()
+    y1 = model(x.cuda(), adj.cuda(), nn_, assign_x=x.cuda())
+    model.eval()
+    with torch.no_grad():
+        y2 = model(x.cuda(), adj.cuda(), nn_, assign_x=x.cuda())
+    close(y1, y2, 0, 0)
+
+
+def test_linearity_of_pooling_at_full_size():
+    """Size-independent property at the DD shape: with S fixed, X' = S^T Z is linear in Z and
+    A' = S^T A S is linear in A (checked through dp_pool_fwd on the full B=20, N=500 batch)."""
+    from graph_pooling_amd import _lib
+    lib = _lib.load()
+    B, n, K, D = 20, 500, 50, 60
+    g = torch.Generator().manual_seed(0)
+    S_ = torch.softmax(torch.randn(B, n, K, generator=g), -1).cuda()
+    Z1, Z2 = torch.randn(B, n, D, generator=g).cuda(), torch.randn(B, n, D, generator=g).cuda()
+    A1 = (torch.rand(B, n, n, generator=g) < 0.02).float().cuda()
+    A2 = (torch.rand(B, n, n, generator=g) < 0.02).float().cuda()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def pool(Z, A):
+        X = torch.empty(B, K, D, device="cuda")
+        Ap = torch.empty(B, K, K, device="cuda")
+        T_ = torch.empty(B, K, n, device="cuda")
+        _lib.check(lib.dp_pool_fwd(S_.data_ptr(), Z.data_ptr(), D, A.data_ptr(), X.data_ptr(), Ap.data_ptr(),
+                                   T_.data_ptr(), B, n, K, D, st))
+        return X, Ap
+    X1, P1 = pool(Z1, A1)
+    X2, P2 = pool(Z2, A2)
+    X3, P3 = pool(Z1 + 2 * Z2, A1 + 2 * A2)
+    close(X3, X1 + 2 * X2, 1e-4, 1e-4)
+    close(P3, P1 + 2 * P2, 1e-4, 1e-4)
+    # every row of S sums to 1  =>  sum(A') == sum(A)  (mass conservation of S^T A S)
+    close(P1.sum(dim=(1, 2)), A1.sum(dim=(1, 2)), 1e-4, 1e-2)

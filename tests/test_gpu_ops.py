@@ -1,0 +1,307 @@
+"""GPU parity of the op-level C-ABI entry points against the CPU oracle (same seeded inputs).
+Every call goes through ctypes into libdiffpool_hip.so — no torch arithmetic on the checked path.
+
+Tolerances: the kernels compute in exact fp32 (f32 MFMA = fma chain), so differences from the oracle
+are reduction-order only: rtol 1e-4 / atol 1e-5 forward, rtol 1e-3 on gradients.
+"""
+import numpy as np
+import pytest
+import torch
+
+from graph_pooling_amd import _lib
+from oracle import diffpool_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available()
+    return _lib.load()
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ws_of(nbytes):
+    return torch.empty(max(int(nbytes), 256), device="cuda", dtype=torch.uint8)
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    torch.testing.assert_close(a.detach().cpu(), b.detach().cpu(), rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------ bgemm
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (50, 60, 500), (500, 40, 500), (89, 20, 37), (33, 129, 65),
+                                   (64, 64, 32), (7, 300, 3)])
+def test_bgemm_shapes(lib, tA, tB, M, N, K):
+    g = torch.Generator().manual_seed(M * 1000 + N * 10 + K)
+    batch = 3
+    A = torch.randn(batch, K, M, generator=g) if tA else torch.randn(batch, M, K, generator=g)
+    Bm = torch.randn(batch, N, K, generator=g) if tB else torch.randn(batch, K, N, generator=g)
+    C0 = torch.randn(batch, M, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    Ad, Bd, Cd, bd = dev(A), dev(Bm), dev(C0), dev(bias)
+    lda, ldb = A.shape[2], Bm.shape[2]
+    rc = lib.dp_bgemm_f32(Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), bd.data_ptr(), batch, M, N, K, lda, ldb, N,
+                          A.shape[1] * lda, Bm.shape[1] * ldb, M * N, tA, tB, 0.5, 2.0, 0, S())
+    _lib.check(rc)
+    opA = A.transpose(1, 2) if tA else A
+    opB = Bm.transpose(1, 2) if tB else Bm
+    ref = 0.5 * (opA.double() @ opB.double()) + 2.0 * C0.double() + bias.double()
+    close(Cd, ref.float(), rtol=1e-4, atol=1e-4)
+
+
+def test_bgemm_asymmetric_identity_and_strides(lib):
+    # A = I with an asymmetric B catches a transposed C-write; leading dims > widths; broadcast B (stride 0)
+    M = N = K = 48
+    A = torch.eye(M).repeat(2, 1, 1)
+    Bm = (torch.arange(K * 70, dtype=torch.float32).reshape(K, 70) * 0.01)
+    Cd = torch.zeros(2, M, 80, device="cuda")
+    Ad, Bd = dev(A), dev(Bm)
+    _lib.check(lib.dp_bgemm_f32(Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), None, 2, M, N, K, K, 70, 80, M * K, 0,
+                                M * 80, 0, 0, 1.0, 0.0, 1, S()))
+    close(Cd[:, :, :N], Bm[:, :N].repeat(2, 1, 1), 0, 0)
+    assert float(Cd[:, :, N:].abs().max()) == 0.0          # nothing written outside the N columns
+
+
+# ------------------------------------------------------------------ A1 GraphConv
+@pytest.mark.parametrize("add_self,bias,normalize", [(0, 1, 1), (1, 1, 1), (0, 0, 1), (1, 0, 0)])
+@pytest.mark.parametrize("B,n,fin,fout", [(3, 16, 5, 8), (2, 100, 89, 20), (2, 37, 20, 50)])
+def test_gcn_layer_fwd_bwd(lib, add_self, bias, normalize, B, n, fin, fout):
+    x, adj, nn_, _ = O.make_batch(B, n, fin, n_min=1, p=0.2, seed=11, onehot=False)
+    g = torch.Generator().manual_seed(5)
+    adj = adj * torch.rand(adj.shape, generator=g)          # general (non-binary, non-symmetric) adjacency
+    W = torch.randn(fin, fout, generator=g) * 0.3
+    b = torch.randn(fout, generator=g) * 0.1 if bias else None
+    dy = torch.randn(B, n, fout, generator=g)
+    xo, ao, Wo = x.clone().requires_grad_(True), adj.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    bo = b.clone().requires_grad_(True) if bias else None
+    yo = O.graph_conv(xo, ao, Wo, bo, bool(add_self), bool(normalize))
+    (yo * dy).sum().backward()
+
+    flags = (1 if add_self else 0) | (2 if normalize else 0)
+    xd, ad, Wd, dyd = dev(x), dev(adj), dev(W), dev(dy)
+    bd = dev(b) if bias else None
+    y = torch.empty(B, n, fout, device="cuda")
+    invn = torch.empty(B, n, device="cuda")
+    wsb = lib.dp_gcn_layer_workspace_bytes(B, n, fin, fout)
+    ws = ws_of(wsb)
+    _lib.check(lib.dp_gcn_layer_fwd(xd.data_ptr(), fin, ad.data_ptr(), Wd.data_ptr(), _lib.ptr(bd), y.data_ptr(), fout,
+                                    invn.data_ptr(), B, n, fin, fout, flags, ws.data_ptr(), wsb, S()))
+    close(y, yo)
+    dx, dadj = torch.empty_like(xd), torch.empty_like(ad)
+    dW, db = torch.empty_like(Wd), torch.empty(fout, device="cuda")
+    _lib.check(lib.dp_gcn_layer_bwd(xd.data_ptr(), fin, ad.data_ptr(), Wd.data_ptr(), y.data_ptr(), fout,
+                                    invn.data_ptr(), dyd.data_ptr(), fout, dx.data_ptr(), fin, dW.data_ptr(),
+                                    db.data_ptr(), dadj.data_ptr(), B, n, fin, fout, flags, ws.data_ptr(), wsb, S()))
+    close(dx, xo.grad, 1e-3, 1e-5)
+    close(dadj, ao.grad, 1e-3, 1e-5)
+    close(dW, Wo.grad, 1e-3, 1e-4)
+    if bias:
+        close(db, bo.grad, 1e-3, 1e-4)
+
+
+def test_gcn_layer_zero_rows_use_the_clamp_branch(lib):
+    # rows with ||u|| < 1e-12 (padded rows with zero bias): y = 0 and d u = d y / 1e-12 (F.normalize's clamp_min)
+    B, n, f = 1, 8, 4
+    x = torch.zeros(B, n, f)
+    x[0, :3] = torch.randn(3, f)
+    adj = torch.zeros(B, n, n)
+    adj[0, :3, :3] = 1.0
+    W = torch.randn(f, f)
+    xd, ad, Wd = dev(x), dev(adj), dev(W)
+    y = torch.empty(B, n, f, device="cuda")
+    invn = torch.empty(B, n, device="cuda")
+    wsb = lib.dp_gcn_layer_workspace_bytes(B, n, f, f)
+    ws = ws_of(wsb)
+    _lib.check(lib.dp_gcn_layer_fwd(xd.data_ptr(), f, ad.data_ptr(), Wd.data_ptr(), None, y.data_ptr(), f,
+                                    invn.data_ptr(), B, n, f, f, 2, ws.data_ptr(), wsb, S()))
+    assert float(y[0, 3:].abs().max()) == 0.0
+    assert float(invn[0, 3:].min()) == pytest.approx(1e12, rel=1e-6)
+    yo = O.graph_conv(x, adj, W, None, False, True)
+    close(y, yo)
+
+
+# ------------------------------------------------------------------ A3 apply_bn
+@pytest.mark.parametrize("relu", [0, 1])
+def test_bn_node_fwd_bwd(lib, relu, golden):
+    a, _, _ = golden("g2_apply_bn")
+    x = torch.from_numpy(a["x"])
+    B, n, F_ = x.shape
+    gy = torch.from_numpy(a["gy"])
+    xo = x.clone().requires_grad_(True)
+    yo = O.bn_node(torch.relu(xo) if relu else xo)
+    (yo * gy).sum().backward()
+    if not relu:                                        # golden vector of the reference's own apply_bn
+        close(yo, torch.from_numpy(a["y"]), 1e-5, 1e-6)
+    xd, gyd = dev(x), dev(gy)
+    y = torch.empty_like(xd)
+    stats = torch.empty(n, 2, device="cuda")
+    wsb = lib.dp_bn_node_workspace_bytes(B, n, F_)
+    ws = ws_of(wsb)
+    _lib.check(lib.dp_bn_node_fwd(xd.data_ptr(), F_, y.data_ptr(), F_, stats.data_ptr(), B, n, F_, relu,
+                                  ws.data_ptr(), wsb, S()))
+    close(y, yo, 1e-4, 2e-5)
+    dx = torch.empty_like(xd)
+    _lib.check(lib.dp_bn_node_bwd(xd.data_ptr(), F_, y.data_ptr(), F_, stats.data_ptr(), gyd.data_ptr(), F_,
+                                  dx.data_ptr(), F_, B, n, F_, relu, ws.data_ptr(), wsb, S()))
+    close(dx, xo.grad, 1e-3, 2e-4)
+
+
+# ------------------------------------------------------------------ A5 assignment head
+def test_assign_softmax_mask(lib):
+    B, n, Din, K = 3, 20, 13, 7
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(B, n, Din, generator=g)
+    Wp, bp = torch.randn(K, Din, generator=g) * 0.5, torch.randn(K, generator=g)
+    nn_ = np.array([20, 1, 9], dtype=np.int32)
+    dS = torch.randn(B, n, K, generator=g)
+    zo, Wo, bo = z.clone().requires_grad_(True), Wp.clone().requires_grad_(True), bp.clone().requires_grad_(True)
+    So = torch.softmax(zo @ Wo.t() + bo, dim=-1) * O.node_mask(n, nn_)
+    (So * dS).sum().backward()
+    zd, Wd, bd, dSd = dev(z), dev(Wp), dev(bp), dev(dS)
+    nd = torch.from_numpy(nn_).cuda()
+    Sd = torch.empty(B, n, K, device="cuda")
+    wsb = lib.dp_assign_workspace_bytes(B, n, Din, K)
+    ws = ws_of(wsb)
+    _lib.check(lib.dp_assign_softmax_mask_fwd(zd.data_ptr(), Din, Wd.data_ptr(), bd.data_ptr(), nd.data_ptr(),
+                                              Sd.data_ptr(), B, n, Din, K, ws.data_ptr(), wsb, S()))
+    close(Sd, So)
+    assert float(Sd[1, 1:].abs().max()) == 0.0
+    dz, dW, db = torch.empty_like(zd), torch.empty_like(Wd), torch.empty_like(bd)
+    _lib.check(lib.dp_assign_softmax_mask_bwd(zd.data_ptr(), Din, Wd.data_ptr(), Sd.data_ptr(), dSd.data_ptr(),
+                                              nd.data_ptr(), dz.data_ptr(), Din, dW.data_ptr(), db.data_ptr(), B, n,
+                                              Din, K, ws.data_ptr(), wsb, S()))
+    close(dz, zo.grad, 1e-3, 1e-5)
+    close(dW, Wo.grad, 1e-3, 1e-5)
+    close(db, bo.grad, 1e-3, 1e-5)
+
+
+# ------------------------------------------------------------------ A6 pooling
+@pytest.mark.parametrize("B,n,K,D", [(3, 16, 4, 9), (2, 100, 10, 60), (1, 130, 33, 70)])
+def test_pool_fwd_bwd(lib, B, n, K, D):
+    g = torch.Generator().manual_seed(n)
+    Sm = torch.softmax(torch.randn(B, n, K, generator=g), -1)
+    Z = torch.randn(B, n, D, generator=g)
+    adj = (torch.rand(B, n, n, generator=g) < 0.2).float() * torch.rand(B, n, n, generator=g)   # non-symmetric
+    dX, dA = torch.randn(B, K, D, generator=g), torch.randn(B, K, K, generator=g)
+    So, Zo, Ao = (t.clone().requires_grad_(True) for t in (Sm, Z, adj))
+    Xp = So.transpose(1, 2) @ Zo
+    Ap = So.transpose(1, 2) @ Ao @ So
+    ((Xp * dX).sum() + (Ap * dA).sum()).backward()
+    Sd, Zd, Ad, dXd, dAd = dev(Sm), dev(Z), dev(adj), dev(dX), dev(dA)
+    Xd, Apd, Td = (torch.empty(B, K, D, device="cuda"), torch.empty(B, K, K, device="cuda"),
+                   torch.empty(B, K, n, device="cuda"))
+    _lib.check(lib.dp_pool_fwd(Sd.data_ptr(), Zd.data_ptr(), D, Ad.data_ptr(), Xd.data_ptr(), Apd.data_ptr(),
+                               Td.data_ptr(), B, n, K, D, S()))
+    close(Xd, Xp, 1e-4, 1e-4)
+    close(Apd, Ap, 1e-4, 1e-4)
+    dS = torch.empty_like(Sd)
+    dZ = torch.zeros_like(Zd)
+    dadj = torch.zeros_like(Ad)
+    wsb = lib.dp_pool_bwd_workspace_bytes(B, n, K, D)
+    ws = ws_of(wsb)
+    _lib.check(lib.dp_pool_bwd(Sd.data_ptr(), Zd.data_ptr(), D, Ad.data_ptr(), Td.data_ptr(), dXd.data_ptr(),
+                               dAd.data_ptr(), dS.data_ptr(), dZ.data_ptr(), D, dadj.data_ptr(), B, n, K, D,
+                               ws.data_ptr(), wsb, S()))
+    close(dS, So.grad, 1e-3, 1e-3)
+    close(dZ, Zo.grad, 1e-3, 1e-4)
+    close(dadj, Ao.grad, 1e-3, 1e-4)
+
+
+# ------------------------------------------------------------------ A7 readout
+def test_masked_max(lib):
+    B, n, F_ = 4, 23, 70
+    g = torch.Generator().manual_seed(2)
+    Z = torch.randn(B, n, F_, generator=g)
+    Z[0, :, :5] = -Z[0, :, :5].abs() - 0.1      # all-negative columns: a masked zero row must win
+    Z[1, 2, 7] = Z[1, 5, 7] = 9.0               # tie: first index wins
+    Z[2, 0, 3] = 0.0
+    Z[2, 1:, 3] = -1.0                          # valid max exactly 0 ties with the masked zeros: valid row wins
+    nn_ = np.array([10, 23, 4, 1], dtype=np.int32)
+    dout = torch.randn(B, F_, generator=g)
+    Zo = Z.clone().requires_grad_(True)
+    out_o, _ = (Zo * O.node_mask(n, nn_)).max(dim=1)
+    (out_o * dout).sum().backward()
+    Zd, dd = dev(Z), dev(dout)
+    nd = torch.from_numpy(nn_).cuda()
+    out = torch.empty(B, F_, device="cuda")
+    arg = torch.empty(B, F_, device="cuda", dtype=torch.int32)
+    _lib.check(lib.dp_masked_max_fwd(Zd.data_ptr(), F_, nd.data_ptr(), out.data_ptr(), F_, arg.data_ptr(), B, n, F_,
+                                     S()))
+    close(out, out_o, 0, 0)
+    assert int(arg[1, 7]) == 2 and int(arg[0, 0]) == -1 and int(arg[2, 3]) == 0
+    dZ = torch.zeros_like(Zd)
+    _lib.check(lib.dp_masked_max_bwd(dd.data_ptr(), F_, arg.data_ptr(), dZ.data_ptr(), F_, B, n, F_, S()))
+    close(dZ, Zo.grad, 0, 0)
+    # no mask at all (base encoder / pooled levels)
+    _lib.check(lib.dp_masked_max_fwd(Zd.data_ptr(), F_, None, out.data_ptr(), F_, arg.data_ptr(), B, n, F_, S()))
+    close(out, Z.max(dim=1)[0], 0, 0)
+
+
+# ------------------------------------------------------------------ A8 link loss
+@pytest.mark.parametrize("B,n,K", [(3, 16, 4), (2, 100, 10)])
+def test_linkpred_loss(lib, B, n, K):
+    g = torch.Generator().manual_seed(K)
+    _, adj, nn_, _ = O.make_batch(B, n, 3, n_min=1, p=0.2, seed=K)
+    Sm = torch.softmax(torch.randn(B, n, K, generator=g) * 2, -1) * O.node_mask(n, nn_)
+    Sm[0, 0] = 0.0
+    Sm[0, 0, 1] = 1.0        # a one-hot row: (S S^T)_00 == 1 exactly -> the tie branch of torch.min
+    So = Sm.clone().requires_grad_(True)
+    lo = O.link_pred_loss(So, adj, nn_)
+    (lo * 1.7).backward()
+    Sd, Ad = dev(Sm), dev(adj)
+    nd = torch.from_numpy(nn_).cuda()
+    loss = torch.empty(1, device="cuda")
+    wsb = lib.dp_linkpred_workspace_bytes(B, n, K)
+    ws = ws_of(wsb)
+    _lib.check(lib.dp_linkpred_loss_fwd(Sd.data_ptr(), Ad.data_ptr(), nd.data_ptr(), loss.data_ptr(), B, n, K,
+                                        ws.data_ptr(), wsb, S()))
+    close(loss[0], lo, 1e-5, 1e-6)
+    dS = torch.empty_like(Sd)
+    dl = torch.tensor([1.7], device="cuda")
+    _lib.check(lib.dp_linkpred_loss_bwd(Sd.data_ptr(), Ad.data_ptr(), nd.data_ptr(), dl.data_ptr(), dS.data_ptr(), 0,
+                                        B, n, K, ws.data_ptr(), wsb, S()))
+    close(dS, So.grad, 1e-3, 1e-5)
+
+
+def test_cross_entropy(lib):
+    B, Cc = 20, 6
+    g = torch.Generator().manual_seed(1)
+    logits = torch.randn(B, Cc, generator=g) * 3
+    label = torch.randint(0, Cc, (B,), generator=g)
+    lo_in = logits.clone().requires_grad_(True)
+    lo = torch.nn.functional.cross_entropy(lo_in, label)
+    lo.backward()
+    ld, yd = dev(logits), label.cuda()
+    loss = torch.empty(1, device="cuda")
+    prob = torch.empty(B, Cc, device="cuda")
+    _lib.check(lib.dp_cross_entropy_fwd(ld.data_ptr(), yd.data_ptr(), loss.data_ptr(), prob.data_ptr(), B, Cc, S()))
+    close(loss[0], lo, 1e-5, 1e-6)
+    dl = torch.empty_like(ld)
+    _lib.check(lib.dp_cross_entropy_bwd(prob.data_ptr(), yd.data_ptr(), None, dl.data_ptr(), B, Cc, S()))
+    close(dl, lo_in.grad, 1e-4, 1e-6)
+
+
+# ------------------------------------------------------------------ A9 mean aggregator
+def test_mean_aggregator_golden(lib, golden):
+    a, _, _ = golden("g8_mean_aggregator")
+    from graph_pooling_amd.aggregators import mean_aggregate
+    table = torch.from_numpy(a["table"]).cuda().requires_grad_(True)
+    ip = torch.from_numpy(a["indptr"].astype(np.int32)).cuda()
+    idx = torch.from_numpy(a["indices"].astype(np.int32)).cuda()
+    out = mean_aggregate(table, ip, idx)
+    close(out, torch.from_numpy(a["out"]), 1e-5, 1e-6)
+    g = torch.randn(out.shape, generator=torch.Generator().manual_seed(0))
+    (out * g.cuda()).sum().backward()
+    to = torch.from_numpy(a["table"]).requires_grad_(True)
+    neighs = [a["indices"][a["indptr"][i]:a["indptr"][i + 1]].tolist() for i in range(len(a["indptr"]) - 1)]
+    (O.mean_aggregate(to, a["nodes"].tolist(), neighs) * g).sum().backward()
+    close(table.grad, to.grad, 1e-4, 1e-6)
