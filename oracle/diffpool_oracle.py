@@ -54,8 +54,9 @@ def graph_conv(x: Tensor, adj: Tensor, weight: Tensor, bias: Optional[Tensor],
     if bias is not None:
         y = y + bias
     if normalize:
-        nrm = y.pow(2).sum(dim=2, keepdim=True).sqrt().clamp_min(L2_EPS)
-        y = y / nrm
+        # the op the reference names at encoders.py:972; its backward is finite at all-zero rows
+        # (padded rows with zero bias), where a hand-written sqrt() would give 0/0
+        y = F.normalize(y, p=2, dim=2, eps=L2_EPS)
     return y
 
 

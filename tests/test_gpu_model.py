@@ -20,6 +20,7 @@ T = torch.from_numpy
 def close(a, b, rtol=1e-4, atol=1e-5):
     a = a.detach().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(a)
     b = b.detach().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(b)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all(), 'non-finite values in a parity check'
     torch.testing.assert_close(a.float(), b.float(), rtol=rtol, atol=atol)
 
 

@@ -33,7 +33,9 @@ def ws_of(nbytes):
 
 
 def close(a, b, rtol=1e-4, atol=1e-5):
-    torch.testing.assert_close(a.detach().cpu(), b.detach().cpu(), rtol=rtol, atol=atol)
+    a, b = a.detach().cpu(), b.detach().cpu()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all(), 'non-finite values in a parity check'
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
 
 
 # ------------------------------------------------------------------ bgemm

@@ -13,6 +13,7 @@ T = torch.from_numpy
 def close(a, b, rtol=1e-5, atol=1e-6):
     a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = b.detach().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert np.isfinite(a).all() and np.isfinite(b).all(), "non-finite values in a parity check"
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
