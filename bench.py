@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py — graphs/sec, forward + loss + backward, of the MI355X DiffPool path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dd|enzymes|er] [--linkpred] [--no-graph]
+
+Metric (BASELINE.json): graphs/sec fwd+bwd on a DD-shaped padded batch (B=20 per GPU, N_max=500, F=89,
+H=E=20, K=50, 3 GCN layers, 1 pooling level, C=2; synthetic seeded data, reference-style init).
+A "step" = SoftPoolingGcnEncoder.forward + .loss + loss.backward() on one resident batch (+ the flat
+gradient all-reduce over RCCL when N > 1).  No optimizer, no H2D.
+
+For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU; the batch is
+sharded by graph (weak scaling: 20 graphs per GPU), and the only collective is one all-reduce of the
+flat gradient buffer per step.
+
+Rank 0 prints ONE JSON line with the driver's fields plus
+  "roofline":     dominant kernel (the level-0 aggregation pass  U = A · [X W_e | X W_a]), algorithmic bytes
+                  per launch / its average duration measured with HIP events on the launch stream
+  "cpu_baseline": the CPU oracle (oracle/diffpool_oracle.py, a torch-CPU restatement pinned to the
+                  reference by tests/golden) timed on this host on the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: B per GPU, N, F, H, C, ratio, p(edge), n_min, onehot
+    "dd": dict(B=20, N=500, F=89, H=20, C=2, ratio=0.1, p=0.02, n_min=30, onehot=True,
+               name="S-DD: DD-shaped padded batch, B=20/GPU, N_max=500, F=89, H=E=20, K=50, L=3, 1 pool"),
+    "enzymes": dict(B=20, N=100, F=3, H=20, C=6, ratio=0.1, p=0.10, n_min=10, onehot=True,
+                    name="S-ENZ: ENZYMES-shaped padded batch, B=20/GPU, N=100, F=3, H=E=20, K=10"),
+    "er": dict(B=256, N=1024, F=64, H=20, C=2, ratio=0.25, p=0.01, n_min=1024, onehot=False,
+               name="S-ER: Erdos-Renyi B=256, N=1024, F=64, K=256, H=E=20, 1 pool"),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_model_and_batch(w, linkpred, device, seed_offset=0):
+    from graph_pooling_amd.encoders import SoftPoolingGcnEncoder
+    from oracle import diffpool_oracle as O          # synthetic batch generator + reference-style init only
+    x, adj, nn_, label = O.make_batch(w["B"], w["N"], w["F"], n_min=w["n_min"], p=w["p"], seed=1 + seed_offset,
+                                      n_classes=w["C"], onehot=w["onehot"])
+    model = SoftPoolingGcnEncoder(w["N"], w["F"], w["H"], w["H"], w["C"], 3, w["H"], assign_ratio=w["ratio"],
+                                  linkpred=linkpred)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    params = O.init_params(shapes, seed=0)
+    model.load_state_dict(params)
+    model = model.to(device)
+    batch = dict(x=x.to(device), adj=adj.to(device), nn=torch.from_numpy(nn_).to(device), label=label.to(device))
+    cpu = dict(x=x, adj=adj, nn=nn_, label=label, params=params)
+    return model, batch, cpu
+
+
+def cpu_baseline(cpu, w, linkpred, budget_s=15.0):
+    """Time the CPU oracle (fwd + loss + bwd) on the same batch, bounded to ~budget_s seconds of CPU work.
+    torch's intra-op pool is tried at a few sizes (all host cpus is pathological on many-core hosts for
+    these small matrices); the best is reported with the thread count actually used."""
+    from oracle import diffpool_oracle as O
+    ncpu = os.cpu_count() or 1
+    P = {k: v.clone().requires_grad_(True) for k, v in cpu["params"].items()}
+
+    def step():
+        for v in P.values():
+            v.grad = None
+        y, inter = O.softpool_forward(P, cpu["x"], cpu["adj"], cpu["nn"], cpu["x"])
+        loss, _ = O.softpool_loss(y, cpu["label"], inter["assign_0"], cpu["adj"], cpu["nn"], linkpred)
+        loss.backward()
+
+    cands = sorted({t for t in (1, 8, 16, 32) if t <= ncpu})
+    best = None
+    per = budget_s / len(cands)
+    for t in cands:
+        torch.set_num_threads(t)
+        step()
+        t0 = time.perf_counter()
+        step()
+        one = time.perf_counter() - t0
+        n = int(max(2, min(100, per / max(one, 1e-4))))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        dt = time.perf_counter() - t0
+        gps = w["B"] * n / dt
+        if best is None or gps > best[0]:
+            best = (gps, t, n, dt)
+    gps, t, n, dt = best
+    return dict(value=round(gps, 2), unit="graphs/s", cores=t, kind="port",
+                sample=f"{n} fwd+loss+bwd steps of the same B={w['B']} batch, torch-CPU fp32 oracle, best of "
+                       f"{cands} intra-op threads ({dt:.1f} s at {t} threads; host has {ncpu} cpus)")
+
+
+def roofline_probe(w, device, iters=200):
+    """Average duration of the dominant kernel, HIP events on the launch stream: the level-0 adjacency
+    aggregation  U[b] = A[b] (N x N) · V[b] (N x C),  C = H_embed + H_assign, through the same entry the
+    encoder plan uses (dp_adj_aggregate -> k_aggregate<false, ceil(C/16)>).
+    Algorithmic bytes per launch = B*N*N*4 (A, fp32 as the caller delivers it) + 2*B*N*C*4 (V read, U written)."""
+    from graph_pooling_amd import _lib
+    lib = _lib.load()
+    B, N, Cc = w["B"], w["N"], 2 * w["H"]
+    A = (torch.rand(B, N, N, device=device) < w["p"]).float()
+    V = torch.randn(B, N, Cc, device=device)
+    U = torch.empty(B, N, Cc, device=device)
+    st = torch.cuda.current_stream()
+
+    def launch():
+        _lib.check(lib.dp_adj_aggregate(A.data_ptr(), V.data_ptr(), Cc, U.data_ptr(), Cc, B, N, Cc, 0, 0.0,
+                                        st.cuda_stream))
+    for _ in range(20):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        launch()
+    e1.record(st)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1000.0 / iters
+    bytes_alg = B * N * N * 4 + 2 * B * N * Cc * 4
+    achieved = bytes_alg / (us * 1e-6) / 1e9
+    return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                kernel=f"k_aggregate<false,{(Cc + 15) // 16}> (level-0 adjacency aggregation A·[XW_e|XW_a])",
+                us_per_launch=round(us, 2), algorithmic_bytes=bytes_alg)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="dd", choices=sorted(WORKLOADS))
+    ap.add_argument("--linkpred", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the DiffPool HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} rank(s)", file=sys.stderr)
+
+    w = WORKLOADS[args.workload]
+    model, batch, cpu = make_model_and_batch(w, args.linkpred, device, seed_offset=rank)
+    dp = None
+    if world > 1:
+        from graph_pooling_amd.parallel import DataParallelEncoder
+        dp = DataParallelEncoder(model)
+
+    def fwd_bwd():
+        model.zero_grad(set_to_none=True)
+        ypred = model(batch["x"], batch["adj"], batch["nn"], assign_x=batch["x"])
+        if args.linkpred:
+            loss = model.loss(ypred, batch["label"], batch["adj"], batch["nn"])
+        else:
+            loss = model.loss(ypred, batch["label"])
+        loss.backward()
+        return loss
+
+    # ---- optional hipGraph capture of the whole fwd+loss+bwd launch sequence
+    graph = None
+    side = torch.cuda.Stream(device)
+    if not args.no_graph:
+        try:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fwd_bwd()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            model.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g):
+                static_loss = fwd_bwd()
+            graph = g
+        except Exception as e:                      # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly",
+                      file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            fwd_bwd()
+        if dp is not None:
+            dp.reduce_gradients()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = w["B"] * world * args.steps / dt
+        out = {
+            "metric": "graphs/sec fwd+bwd, DD padded batch N_max=500" if args.workload == "dd"
+                      else f"graphs/sec fwd+bwd, {args.workload}",
+            "value": round(value, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["name"], "graphs_per_gpu": w["B"], "global_batch": w["B"] * world,
+                       "linkpred": bool(args.linkpred), "hip_graph": graph is not None,
+                       "parallelism": f"dp{world}"},
+        }
+        if world == 1:
+            out["roofline"] = roofline_probe(w, device)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(cpu, w, args.linkpred)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,316 @@
+// Adjacency aggregation  U[b] = op(A[b]) · V[b]   with A [n x n] fp32 as delivered by the caller and
+// V [n x C] a narrow feature panel (C <= 128) — GraphConv's `torch.matmul(adj, x)` (encoders.py:965),
+// its transpose in the backward pass, and the adjacency passes of the pooling step (encoders.py:1279).
+//
+// This is the pass that touches the padded dense adjacency, the only large operand of the DiffPool
+// path (B*N*N*4 bytes: 20 MB at the DD shape against 1.6 MB of features), so it is HBM-bound and the
+// design goal is bytes in flight, not MFMA rate:
+//   * one workgroup = 32 output rows of one graph; its whole adjacency panel (32 x n, or n x 32 for the
+//     transposed pass) is requested at once with direct-to-LDS loads (global_load_lds_dwordx4, 1 KiB per
+//     wave instruction, full 128-B lines, no VGPR staging) -> every byte of A is in flight right after
+//     launch (320 workgroups x 64 KB = the whole 20 MB at the DD shape)
+//   * the four waves split K; V fragments come straight from L2 (V is re-read by the 16 row tiles of a
+//     graph but is only n*C*4 = 80 KB) with a one-step register prefetch
+//   * exact fp32 MFMA (16x16x4), partial tiles reduced across waves through LDS, then the epilogue:
+//     plain store (optionally accumulating), or the fused GraphConv tail  (+P) + bias -> l2-normalise ->
+//     (ReLU statistics for apply_bn)  of encoders.py:966-972 / 1062-1064.
+// NN panel image: [32][ldp], ldp = 4 mod 64 floats  -> ds_read_b128 fragment reads are conflict-free
+//                 (each lane reads 4 consecutive k; the V fragment loads use the same k order)
+// TN panel image: [n][32] (8 rows per 1-KiB DMA piece) -> ds_read_b32, 2-way conflicts (minor next to
+//                 the 32-cycle MFMA)
+#include "dp_common.h"
+
+namespace dp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define AGG_L2_EPS 1e-12f
+
+struct AggArgs {
+    const float* A;      // [B, n, n]
+    const float* V;      // [B, n, C] (ldv)
+    int ldv;
+    int n, C;
+    // plain epilogue
+    float* U;            // [B, n, C] (ldu) or null
+    int ldu;
+    float beta;          // U = acc + beta * U
+    // fused GraphConv epilogue (NN only), U == null
+    const float* P;      // add_self operand (same layout as V) or null
+    GroupCPtrs bias;
+    RowGroups g;
+    GroupPtrs yout;
+    float* invn;         // [B, n, G]
+    float* part;         // [B, n, G, 2] or null
+    int normalize, stats_mode;
+};
+
+constexpr int AGG_RT = 32;         // output rows per workgroup
+constexpr int AGG_KP = 1024;       // K columns per LDS panel (NN); 128-KiB panels at most
+
+__device__ inline void dma16(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__device__ inline float agg_team_sum(float v) {
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    return v;
+}
+
+template <bool TRANS, int CT>
+__global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * AGG_RT;
+    const int n = a.n;
+    const float* A = a.A + (long)b * n * n;
+    const float* V = a.V + (long)b * n * a.ldv;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int kpanel = TRANS ? n : min(n, AGG_KP);
+    const int segs = (kpanel + 255) / 256;
+    const int ldp = TRANS ? 32 : segs * 256 + 4;      // NN: = 4 (mod 64)
+
+    for (int kbase = 0; kbase < n; kbase += kpanel) {
+        const int kw = min(kpanel, n - kbase);        // valid K columns in this panel
+        // ---------------- V fragments for this wave's first TWO steps go out ahead of the panel burst, so
+        // they are not queued behind 64 KB of adjacency in this CU's memory pipeline
+        const int steps = (kw + 15) / 16;
+        float bv[4][CT], bn[4][CT], bn2[4][CT];
+        auto load_b = [&](int step, float (&dst)[4][CT]) {
+            const int k0 = kbase + step * 16 + kq * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j;
+                const bool kok = (step < steps) && (k < kbase + kw);
+#pragma unroll
+                for (int cb = 0; cb < CT; ++cb) {
+                    const int c = cb * 16 + l15;
+                    dst[j][cb] = (kok && c < a.C) ? V[(long)k * a.ldv + c] : 0.f;
+                }
+            }
+        };
+        load_b(wave, bv);
+        load_b(wave + 4, bn);
+        // ---------------- panel -> LDS (everything in flight at once)
+        if (!TRANS) {
+            // rows r0..r0+31, columns kbase..kbase+kw: pieces (row i, segment s) of 256 floats
+            const int pieces = AGG_RT * segs;
+            for (int pc = wave; pc < pieces; pc += 4) {
+                const int i = pc / segs, s = pc % segs;
+                const int row = min(r0 + i, n - 1);
+                int col = kbase + s * 256 + lane * 4;
+                col = min(col, n - 4);                 // clamp: finite duplicates, multiplied by zero V rows
+                dma16(A + (long)row * n + col, lds + i * ldp + s * 256);
+            }
+        } else {
+            // columns r0..r0+31 of rows k: pieces of 8 rows x 128 B; every row a k-step can touch is
+            // written (rows >= n are finite duplicates of row n-1 and meet zero V rows)
+            const int pieces = ((kw + 15) / 16) * 2;
+            for (int pc = wave; pc < pieces; pc += 4) {
+                const int k = min(kbase + pc * 8 + (lane >> 3), n - 1);
+                const int col = min(r0 + (lane & 7) * 4, n - 4);
+                dma16(A + (long)k * n + col, lds + pc * 256);
+            }
+        }
+        __syncthreads();                               // drains the DMA (vmcnt(0)) and publishes the panel
+        for (int step = wave; step < steps; step += 4) {
+            load_b(step + 8, bn2);
+            const int kl = step * 16 + kq * 4;         // panel-local k of this lane's 4 values
+            float av[2][4];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                if (!TRANS) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(lds + (rb * 16 + l15) * ldp + kl);
+                    av[rb][0] = t[0]; av[rb][1] = t[1]; av[rb][2] = t[2]; av[rb][3] = t[3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) av[rb][j] = lds[(kl + j) * 32 + rb * 16 + l15];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < CT; ++cb)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][j], bv[j][cb], acc[rb][cb], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int cb = 0; cb < CT; ++cb) {
+                    bv[j][cb] = bn[j][cb];
+                    bn[j][cb] = bn2[j][cb];
+                }
+        }
+        __syncthreads();                               // panel may be overwritten (next K panel / reduction)
+    }
+
+    // ---------------- cross-wave reduction through LDS: red[wave][32][CTP]
+    constexpr int CTP = CT * 16 + 1;
+    float* red = lds;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CT; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[(wave * AGG_RT + rb * 16 + kq * 4 + r) * CTP + cb * 16 + l15] = acc[rb][cb][r];
+    __syncthreads();
+    float* tile = lds + 4 * AGG_RT * CTP;              // summed tile [32][CTP]
+    for (int e = threadIdx.x; e < AGG_RT * CT * 16; e += 256) {
+        const int r = e / (CT * 16), c = e % (CT * 16);
+        const float s = red[(0 * AGG_RT + r) * CTP + c] + red[(1 * AGG_RT + r) * CTP + c] +
+                        red[(2 * AGG_RT + r) * CTP + c] + red[(3 * AGG_RT + r) * CTP + c];
+        if (a.U) {
+            const int row = r0 + r;
+            if (row < n && c < a.C) {
+                float* u = a.U + ((long)b * n + row) * a.ldu + c;
+                *u = (a.beta != 0.f) ? s + a.beta * (*u) : s;
+            }
+        } else {
+            tile[r * CTP + c] = s;
+        }
+    }
+    if (a.U) return;
+    __syncthreads();
+
+    // ---------------- fused GraphConv tail (encoders.py:966-972): one 16-lane team per (row, group)
+    const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
+    for (int it = team; it < AGG_RT * a.g.G; it += 16) {
+        const int r = it / a.g.G, g = it % a.g.G;
+        const int node = r0 + r;
+        if (node >= n) continue;
+        const long row = (long)b * n + node;
+        const int c0 = a.g.c0[g], w = a.g.w[g];
+        const float* u = tile + r * CTP + c0;
+        const float* p = a.P ? a.P + row * a.ldv + c0 : nullptr;
+        const float* bias = a.bias.p[g];
+        float ss = 0.f;
+        for (int c = tl; c < w; c += 16) {
+            float v = u[c];
+            if (p) v += p[c];
+            if (bias) v += bias[c];
+            ss += v * v;
+        }
+        ss = agg_team_sum(ss);
+        const float inv = a.normalize ? 1.f / fmaxf(sqrtf(ss), AGG_L2_EPS) : 1.f;
+        float* y = a.yout.p[g] + row * a.yout.ld[g];
+        float s1 = 0.f;
+        for (int c = tl; c < w; c += 16) {
+            float v = u[c];
+            if (p) v += p[c];
+            if (bias) v += bias[c];
+            v *= inv;
+            y[c] = v;
+            s1 += a.stats_mode == 1 ? fmaxf(v, 0.f) : v;
+        }
+        if (tl == 0 && a.invn) a.invn[row * a.g.G + g] = inv;
+        if (a.stats_mode && a.part) {
+            s1 = agg_team_sum(s1);
+            const float mean = s1 / (float)w;
+            float m2 = 0.f;
+            for (int c = tl; c < w; c += 16) {
+                float v = u[c];
+                if (p) v += p[c];
+                if (bias) v += bias[c];
+                v *= inv;
+                if (a.stats_mode == 1) v = fmaxf(v, 0.f);
+                v -= mean;
+                m2 += v * v;
+            }
+            m2 = agg_team_sum(m2);
+            if (tl == 0) {
+                a.part[(row * a.g.G + g) * 2 + 0] = mean;
+                a.part[(row * a.g.G + g) * 2 + 1] = m2;
+            }
+        }
+    }
+}
+
+static size_t agg_lds_bytes(bool trans, int n, int CT) {
+    const int kpanel = trans ? n : (n < AGG_KP ? n : AGG_KP);
+    const int segs = (kpanel + 255) / 256;
+    const size_t panel = trans ? (size_t)((n + 15) / 16) * 512 : (size_t)AGG_RT * (segs * 256 + 4);
+    const size_t red = (size_t)5 * AGG_RT * (CT * 16 + 1);
+    return (panel > red ? panel : red) * sizeof(float);
+}
+
+bool aggregate_supported(const float* A, int n, int C, bool trans) {
+    if (n < 4 || n % 4 != 0 || C < 1 || C > 128) return false;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) != 0) return false;
+    return agg_lds_bytes(trans, n, (C + 15) / 16) <= 160 * 1024;
+}
+
+template <bool TRANS, int CT>
+static void launch_agg(Seq& q, const AggArgs& a, int B) {
+    const size_t lds = agg_lds_bytes(TRANS, a.n, CT);
+    static bool attr_done = false;   // per instantiation: allow > 64 KiB of dynamic LDS
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate<TRANS, CT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_aggregate<TRANS, CT>), dim3((a.n + AGG_RT - 1) / AGG_RT, B), dim3(256), lds, q.stream, a);
+}
+
+template <bool TRANS>
+static void dispatch_ct(Seq& q, const AggArgs& a, int B) {
+    switch ((a.C + 15) / 16) {
+        case 1: launch_agg<TRANS, 1>(q, a, B); break;
+        case 2: launch_agg<TRANS, 2>(q, a, B); break;
+        case 3: launch_agg<TRANS, 3>(q, a, B); break;
+        case 4: launch_agg<TRANS, 4>(q, a, B); break;
+        case 5: launch_agg<TRANS, 5>(q, a, B); break;
+        case 6: launch_agg<TRANS, 6>(q, a, B); break;
+        case 7: launch_agg<TRANS, 7>(q, a, B); break;
+        default: launch_agg<TRANS, 8>(q, a, B); break;
+    }
+}
+
+// U[b] (ldu) = op(A[b]) V[b] (+ beta U[b]);  falls back to the generic GEMM for shapes the panel kernel
+// does not take (n not a multiple of 4, C > 128, unaligned A).
+void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ldu, int B, int n, int C, bool trans,
+               float beta) {
+    if (!q.ok()) return;
+    if (!aggregate_supported(A, n, C, trans)) {
+        bgemm(q, A, V, U, nullptr, B, n, C, n, n, ldv, ldu, (long)n * n, (long)n * ldv, (long)n * ldu, trans, false,
+              1.f, beta, 0);
+        return;
+    }
+    AggArgs a{};
+    a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = U; a.ldu = ldu; a.beta = beta;
+    if (trans) dispatch_ct<true>(q, a, B); else dispatch_ct<false>(q, a, B);
+    q.check_launch("aggregate");
+}
+
+// Fused forward GraphConv tail: y = l2norm(A V (+ P) + bias) per column group, written to yout, with the
+// apply_bn partial statistics.  Returns false (nothing launched) when the shape needs the generic path.
+bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, const float* P, GroupCPtrs bias,
+                           RowGroups g, GroupPtrs yout, float* invn, float* part, int B, int n, int normalize,
+                           int stats_mode) {
+    const int C = g.c0[g.G - 1] + g.w[g.G - 1];
+    if (!aggregate_supported(A, n, C, false)) return false;
+    if (!q.ok()) return true;
+    AggArgs a{};
+    a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = nullptr;
+    a.P = P; a.bias = bias; a.g = g; a.yout = yout; a.invn = invn; a.part = part;
+    a.normalize = normalize; a.stats_mode = stats_mode;
+    dispatch_ct<false>(q, a, B);
+    q.check_launch("aggregate_rownorm_fwd");
+    return true;
+}
+
+}  // namespace dp

@@ -67,10 +67,14 @@ void gcn_layer_fwd_seq(Seq& q, const float* x, int ldx, const float* adj, const 
     if (q.err) return;
     bgemm(q, x, W, P, nullptr, B, n, Fout, Fin, ldx, Fout, Fout, (long)n * ldx, 0, (long)n * Fout, false, false, 1.f,
           0.f, 0);
-    bgemm(q, adj, P, U, nullptr, B, n, Fout, n, n, Fout, Fout, (long)n * n, (long)n * Fout, (long)n * Fout, false,
-          false, 1.f, 0.f, 0);
-    rownorm_fwd(q, U, Fout, (flags & DP_F_ADD_SELF) ? P : nullptr, gcp(bias, 0), one_group(Fout), gp(y, ldy), invn,
-                nullptr, (long)B * n, (flags & DP_F_NORMALIZE) ? 1 : 0, 0);
+    const float* selfp = (flags & DP_F_ADD_SELF) ? P : nullptr;
+    const int norm = (flags & DP_F_NORMALIZE) ? 1 : 0;
+    if (!aggregate_rownorm_fwd(q, adj, P, Fout, selfp, gcp(bias, 0), one_group(Fout), gp(y, ldy), invn, nullptr, B, n,
+                               norm, 0)) {
+        bgemm(q, adj, P, U, nullptr, B, n, Fout, n, n, Fout, Fout, (long)n * n, (long)n * Fout, (long)n * Fout, false,
+              false, 1.f, 0.f, 0);
+        rownorm_fwd(q, U, Fout, selfp, gcp(bias, 0), one_group(Fout), gp(y, ldy), invn, nullptr, (long)B * n, norm, 0);
+    }
 }
 
 void gcn_layer_bwd_seq(Seq& q, const float* x, int ldx, const float* adj, const float* W, const float* y, int ldy,
@@ -81,11 +85,10 @@ void gcn_layer_bwd_seq(Seq& q, const float* x, int ldx, const float* adj, const 
     float* P = dadj ? q.alloc<float>((size_t)B * n * Fout) : nullptr;
     if (q.err) return;
     const int norm = (flags & DP_F_NORMALIZE) ? 1 : 0;
-    rownorm_bwd(q, gcp(dy, lddy), gcp(nullptr, 0), gcp(y, ldy), invn, nullptr, nullptr, one_group(Fout), dU, Fout, B, n,
-                0, 0, norm);
+    rownorm_bwd(q, gcp(dy, lddy), gcp(nullptr, 0), gcp(y, ldy), invn, nullptr, nullptr, one_group(Fout), dU, Fout,
+                nullptr, B, n, 0, 0, norm);
     if (db) colsum_batched(q, dU, Fout, 0, B * n, Fout, db, 0, 1);
-    bgemm(q, adj, dU, G, nullptr, B, n, Fout, n, n, Fout, Fout, (long)n * n, (long)n * Fout, (long)n * Fout, true, false,
-          1.f, 0.f, 0);
+    aggregate(q, adj, dU, Fout, G, Fout, B, n, Fout, true, 0.f);
     if (flags & DP_F_ADD_SELF) axpy(q, G, dU, 1.f, (long)B * n * Fout);
     // dW = sum_b x_b^T G_b: one contraction over K = B*n rows (x rows of consecutive graphs are ldx apart)
     bgemm(q, x, G, dW, nullptr, 1, Fin, Fout, B * n, ldx, Fout, Fout, 0, 0, 0, true, false, 1.f, 0.f, 0);
@@ -106,23 +109,18 @@ void bn_fwd_seq(Seq& q, const float* x, int ldx, float* y, int ldy, float* stats
     if (q.err) return;
     RowGroups g = one_group(F);
     rownorm_fwd(q, x, ldx, nullptr, gcp(nullptr, 0), g, gp(tmp, F), nullptr, part, (long)B * n, 0, relu ? 1 : 2);
-    bn_finalize(q, part, stats, B, n, g);
-    bn_apply_fwd(q, tmp, F, stats, g, gp(y, ldy), B, n, relu);
+    bn_apply_fwd(q, tmp, F, part, stats, g, gp(y, ldy), B, n, relu);
 }
 
 void bn_bwd_seq(Seq& q, const float* x, int ldx, const float* y, int ldy, const float* stats, const float* dy, int lddy,
                 float* dx, int lddx, int B, int n, int F, int relu) {
     float* part = q.alloc<float>((size_t)B * n * 2);
-    float* means = q.alloc<float>((size_t)n * 2);
-    float* ones = q.alloc<float>((size_t)B * n);   // unused invn slot (normalize = 0)
-    (void)ones;
     if (q.err) return;
     RowGroups g = one_group(F);
     bn_bwd_partials(q, gcp(dy, lddy), gcp(y, ldy), g, part, (long)B * n);
-    sum_finalize(q, part, means, B, n, g);
     // "y" operand of rownorm_bwd is only used for the ReLU mask: the forward input x
-    rownorm_bwd(q, gcp(dy, lddy), gcp(y, ldy), gcp(relu ? x : y, relu ? ldx : ldy), nullptr, stats, means, g, dx, lddx,
-                B, n, relu, 1, 0);
+    rownorm_bwd(q, gcp(dy, lddy), gcp(y, ldy), gcp(relu ? x : y, relu ? ldx : ldy), nullptr, stats, part, g, dx, lddx,
+                nullptr, B, n, relu, 1, 0);
 }
 
 void assign_fwd_seq(Seq& q, const float* z, int ldz, const float* Wp, const float* bp, const int* num_nodes, float* S,
@@ -234,6 +232,16 @@ int dp_bgemm_f32(const float* A, const float* B, float* C, const float* bias, in
     Seq q(STREAM(stream), nullptr, 0);
     bgemm(q, A, B, C, bias, batch, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, transA != 0, transB != 0, alpha,
           beta, act);
+    return q.err;
+}
+
+int dp_adj_aggregate(const float* adj, const float* V, int ldv, float* U, int ldu, int B, int n, int C, int trans,
+                     float beta, void* stream) {
+    NOTNULL(adj); NOTNULL(V); NOTNULL(U);
+    NONNEG(B); NONNEG(n); NONNEG(C);
+    DP_CHECK_ARG(ldv >= C && ldu >= C, "ldv=%d/ldu=%d smaller than C=%d", ldv, ldu, C);
+    Seq q(STREAM(stream), nullptr, 0);
+    aggregate(q, adj, V, ldv, U, ldu, B, n, C, trans != 0, beta);
     return q.err;
 }
 

@@ -87,6 +87,23 @@ void bgemm(Seq& q, const float* A, const float* B, float* C, const float* bias, 
            int K, int lda, int ldb, int ldc, long sA, long sB, long sC, bool tA, bool tB, float alpha,
            float beta, int act);
 
+// Several independent contractions (same batch count) in ONE launch: the DiffPool batches are small, so
+// dependent chains of tiny GEMMs are launch/latency-bound; siblings run side by side in one grid.
+#define GEMM_GROUP_MAX 4
+struct GemmDesc {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int M, N, K;
+    int lda, ldb, ldc;
+    long sA, sB, sC;
+    bool tA, tB;
+    float alpha, beta;
+    int act;
+};
+void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch);
+
 // Column groups of a row: the level-j embed and assign GCN stacks share one pass over the
 // adjacency, so row-wise kernels work on up to two column groups of a joint buffer.
 struct RowGroups {
@@ -107,15 +124,26 @@ struct GroupCPtrs {
 void rownorm_fwd(Seq& q, const float* U, int ldu, const float* P /*add_self or null*/, GroupCPtrs bias,
                  RowGroups g, GroupPtrs yout, float* invn, float* part /*[rows,G,2] or null*/, long rows,
                  int normalize, int relu_stats);
-void bn_finalize(Seq& q, const float* part, float* stats, int B, int n, RowGroups g);
-void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* stats /*null: no BN*/, RowGroups g,
-                  GroupPtrs xout, int B, int n, int relu);
+void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* part /*[B,n,G,2]; null: no BN*/, float* stats,
+                  RowGroups g, GroupPtrs xout, int B, int n, int relu);
 void mask_rows(Seq& q, const float* src, int lds, float* dst, int ldd, const int* num_nodes, int B, int n, int F);
 void bn_bwd_partials(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, RowGroups g, float* part, long rows);
-void sum_finalize(Seq& q, const float* part, float* means, int B, int n, RowGroups g);
 void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat /*BN output, null when no BN*/, GroupCPtrs y,
-                 const float* invn, const float* stats, const float* means, RowGroups g, float* dU, int ldu,
-                 int B, int n, int has_relu, int has_bn, int normalize);
+                 const float* invn, const float* stats, const float* part2, RowGroups g, float* dU, int ldu,
+                 float* bpart /*[B, rownorm_bwd_chunks(n), ldu] column sums of dU, or null*/, int B, int n,
+                 int has_relu, int has_bn, int normalize);
+int rownorm_bwd_chunks(int n);
+struct BiasReduceEntry {
+    const float* src;   // [rows, ld]
+    int rows, ld, c0, w;
+    long dst;           // offset in the flat gradient buffer
+};
+#define BIAS_TABLE_MAX ((DP_MAX_LEVELS + 1) * DP_MAX_LAYERS * 2)
+struct BiasReduceTable {
+    int count;
+    BiasReduceEntry e[BIAS_TABLE_MAX];
+};
+void reduce_bias(Seq& q, const BiasReduceTable& t, float* grads);
 void colsum_batched(Seq& q, const float* X, int ldx, long strideX, int rows, int cols, float* out,
                     long strideOut, int batch);
 void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, const int* num_nodes, int B,
@@ -132,6 +160,13 @@ void ce_bwd(Seq& q, const float* prob, const long long* label, const float* dlos
             int B, int C);
 void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, long count, int accumulate);
 void axpy(Seq& q, float* y, const float* x, float a, long count);
+
+// (dp_agg.hip) adjacency-panel aggregation
+void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ldu, int B, int n, int C, bool trans,
+               float beta);
+bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, const float* P, GroupCPtrs bias,
+                           RowGroups g, GroupPtrs yout, float* invn, float* part, int B, int n, int normalize,
+                           int stats_mode);
 
 // (dp_linkpred.hip)
 void linkpred_fwd(Seq& q, const float* S, int lds, const float* adj, const int* num_nodes, float* loss_out,

@@ -8,12 +8,18 @@
 // every backward contraction.  Arbitrary M, N, K and leading dimensions (the path's sizes are
 // 500, 89, 50, 60 ... — nothing is a multiple of anything), zero-filled edges.
 //
-// Tiling: 256 threads = 4 waves; each wave owns a 32x32 output block = 2x2 MFMA 16x16 tiles
-// (16 accumulator VGPRs); workgroup tile 64x64 (waves 2x2) or 128x32 (waves 4x1) for skinny N.
-// K is walked in 32-wide slabs staged through LDS.  The LDS image of an operand keeps the
-// operand's own memory orientation so global reads and LDS writes are both lane-contiguous:
+// Tiling: 256 threads = 4 waves arranged WAVES_M x WAVES_N over a BM x BN workgroup tile; each wave
+// owns (BM/WAVES_M) x (BN/WAVES_N) as MFMA 16x16 tiles.  The DiffPool batches are small (B = 20 graphs
+// of <= 500 nodes), so the launcher picks the LARGEST tile that still yields >= ~2 workgroups per CU:
+// the kernels are latency-bound, and bytes in flight (Little's law) is what buys bandwidth.
+// K is walked in 32-wide slabs staged through LDS with a two-deep register prefetch (the slab two
+// steps ahead is in flight while the current one is multiplied).  16-byte global loads when the
+// operand's alignment allows.  The LDS image of an operand keeps the operand's own memory
+// orientation so global reads and LDS writes are both lane-contiguous:
 //   k-contiguous operand  -> image [r][k], row stride 34  (frag read bank = 2r + k : conflict-free)
 //   r-contiguous operand  -> image [k][r], row stride = 16 mod 32 (k rows land on disjoint bank halves)
+#include <cstdlib>
+
 #include "dp_common.h"
 
 namespace dp {
@@ -31,74 +37,108 @@ struct GemmArgs {
     float alpha, beta;
     int act;
     int tilesN;
+    int vecA, vecB;   // operand may be read with 16-byte loads
+    int tA, tB;
 };
 
 constexpr int KT = 32;
 
 template <int R, bool KCONTIG>
 struct LdsImage {
-    // KCONTIG: [R][KT+2]; else [KT][R+16]
-    static constexpr int STRIDE = KCONTIG ? (KT + 2) : (R + 16);
+    // r-contiguous rows must start 16 banks apart (stride = 16 mod 32) and stay 16-byte aligned
+    static constexpr int STRIDE = KCONTIG ? (KT + 2) : ((R % 32 == 16) ? R + 32 : R + 16);
     static constexpr int SIZE = KCONTIG ? R * STRIDE : KT * STRIDE;
-    static constexpr int PER_THREAD = R * KT / 256;
     __device__ static inline int addr(int r, int k) { return KCONTIG ? r * STRIDE + k : k * STRIDE + r; }
 };
 
-// Load one R x KT operand slab (rows r0.., k0..) into registers. `KCONTIG`: element (r,k) at p[r*ld + k],
-// else at p[k*ld + r].
+// One R x KT operand slab held in registers as float4 "slots" (R*KT/4 slots over 256 threads).
+template <int R>
+struct Slab {
+    static constexpr int SLOTS = (R * KT / 4 + 255) / 256;
+    f32x4 v[SLOTS];
+};
+
+// `KCONTIG`: element (r,k) at p[r*ld + k], else at p[k*ld + r].
 template <int R, bool KCONTIG>
-__device__ inline void slab_load(const float* __restrict__ p, int ld, int r0, int k0, int rmax, int kmax,
-                                 float (&reg)[R * KT / 256]) {
+__device__ inline void slab_load(const float* __restrict__ p, int ld, int r0, int k0, int rmax, int kmax, bool vec,
+                                 Slab<R>& s) {
     const int t = threadIdx.x;
-    if (KCONTIG) {
-        const int k = t & (KT - 1);
-        const int rr = t >> 5;  // 0..7
 #pragma unroll
-        for (int i = 0; i < R * KT / 256; ++i) {
-            const int r = rr + i * 8;
+    for (int i = 0; i < Slab<R>::SLOTS; ++i) {
+        const int slot = t + i * 256;
+        f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (slot < R * KT / 4) {
+            int r, k;   // first element of the slot; the 4 elements run along the contiguous dimension
+            if (KCONTIG) {
+                r = slot / (KT / 4);
+                k = (slot % (KT / 4)) * 4;
+            } else {
+                k = slot / (R / 4);
+                r = (slot % (R / 4)) * 4;
+            }
             const int gr = r0 + r, gk = k0 + k;
-            reg[i] = (gr < rmax && gk < kmax) ? p[(long)gr * ld + gk] : 0.f;
-        }
-    } else {
-        const int r = t & (R - 1);
-        const int kk = t / R;  // 0 .. 256/R-1
+            if (KCONTIG) {
+                if (gr < rmax) {
+                    const float* q = p + (long)gr * ld + gk;
+                    if (vec && gk + 3 < kmax) {
+                        val = *reinterpret_cast<const f32x4*>(q);
+                    } else {
 #pragma unroll
-        for (int i = 0; i < R * KT / 256; ++i) {
-            const int k = kk + i * (256 / R);
-            const int gr = r0 + r, gk = k0 + k;
-            reg[i] = (gr < rmax && gk < kmax) ? p[(long)gk * ld + gr] : 0.f;
+                        for (int j = 0; j < 4; ++j)
+                            if (gk + j < kmax) val[j] = q[j];
+                    }
+                }
+            } else {
+                if (gk < kmax) {
+                    const float* q = p + (long)gk * ld + gr;
+                    if (vec && gr + 3 < rmax) {
+                        val = *reinterpret_cast<const f32x4*>(q);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (gr + j < rmax) val[j] = q[j];
+                    }
+                }
+            }
         }
+        s.v[i] = val;
     }
 }
 
 template <int R, bool KCONTIG>
-__device__ inline void slab_store(float* lds, const float (&reg)[R * KT / 256]) {
+__device__ inline void slab_store(float* lds, const Slab<R>& s) {
     using L = LdsImage<R, KCONTIG>;
     const int t = threadIdx.x;
-    if (KCONTIG) {
-        const int k = t & (KT - 1);
-        const int rr = t >> 5;
 #pragma unroll
-        for (int i = 0; i < R * KT / 256; ++i) lds[L::addr(rr + i * 8, k)] = reg[i];
-    } else {
-        const int r = t & (R - 1);
-        const int kk = t / R;
-#pragma unroll
-        for (int i = 0; i < R * KT / 256; ++i) lds[L::addr(r, kk + i * (256 / R))] = reg[i];
+    for (int i = 0; i < Slab<R>::SLOTS; ++i) {
+        const int slot = t + i * 256;
+        if (slot < R * KT / 4) {
+            if (KCONTIG) {
+                const int r = slot / (KT / 4), k = (slot % (KT / 4)) * 4;
+                float* d = lds + L::addr(r, k);   // 8-byte aligned (row stride 34 floats)
+                d[0] = s.v[i][0];
+                d[1] = s.v[i][1];
+                d[2] = s.v[i][2];
+                d[3] = s.v[i][3];
+            } else {
+                const int k = slot / (R / 4), r = (slot % (R / 4)) * 4;
+                *reinterpret_cast<f32x4*>(lds + L::addr(r, k)) = s.v[i];   // row stride is a multiple of 16 B
+            }
+        }
     }
 }
 
-template <int BM, int BN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void bgemm_kernel(GemmArgs a) {
-    // A operand: rows = M index, k. Not transposed -> stored [M][K] (k-contiguous).
-    using LA = LdsImage<BM, !TA>;
-    // B operand: rows = N index, k. Not transposed -> stored [K][N] (r-contiguous); transposed -> [N][K].
-    using LB = LdsImage<BN, TB>;
-    __shared__ float lds[LA::SIZE + LB::SIZE];
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB>
+__device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MI = WM / 16, NI = WN / 16;
+    static_assert(MI >= 1 && NI >= 1, "wave tile must be at least 16x16");
+    using LA = LdsImage<BM, !TA>;   // A operand: not transposed -> stored [M][K] (k-contiguous)
+    using LB = LdsImage<BN, TB>;    // B operand: not transposed -> stored [K][N] (r-contiguous)
     float* As = lds;
-    float* Bs = lds + LA::SIZE;
+    float* Bs = lds + ((LA::SIZE + 3) & ~3);
 
-    const int tile = blockIdx.x;
     const int tm = tile / a.tilesN, tn = tile % a.tilesN;
     const int b = blockIdx.y;
     const float* A = a.A + (long)b * a.sA;
@@ -108,55 +148,77 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    constexpr int WAVES_N = BN / 32;
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    f32x4 acc[2][2];
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float ra[LA::PER_THREAD], rb[LB::PER_THREAD];
     const int nk = (a.K + KT - 1) / KT;
-    slab_load<BM, !TA>(A, a.lda, m0, 0, a.M, a.K, ra);
-    slab_load<BN, TB>(B, a.ldb, n0, 0, a.N, a.K, rb);
-    for (int kt = 0; kt < nk; ++kt) {
-        slab_store<BM, !TA>(As, ra);
-        slab_store<BN, TB>(Bs, rb);
-        __syncthreads();
-        if (kt + 1 < nk) {
-            slab_load<BM, !TA>(A, a.lda, m0, (kt + 1) * KT, a.M, a.K, ra);
-            slab_load<BN, TB>(B, a.ldb, n0, (kt + 1) * KT, a.N, a.K, rb);
-        }
+    Slab<BM> ra0, ra1;
+    Slab<BN> rb0, rb1;
+    if (nk > 0) {
+        slab_load<BM, !TA>(A, a.lda, m0, 0, a.M, a.K, a.vecA, ra0);
+        slab_load<BN, TB>(B, a.ldb, n0, 0, a.N, a.K, a.vecB, rb0);
+    }
+    if (nk > 1) {
+        slab_load<BM, !TA>(A, a.lda, m0, KT, a.M, a.K, a.vecA, ra1);
+        slab_load<BN, TB>(B, a.ldb, n0, KT, a.N, a.K, a.vecB, rb1);
+    }
+
+    auto compute = [&]() {
 #pragma unroll
         for (int kk = 0; kk < KT; kk += 4) {
-            float af[2], bf[2];
+            float af[MI], bf[NI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = As[LA::addr(wr * 32 + i * 16 + l15, kk + l4)];
+            for (int i = 0; i < MI; ++i) af[i] = As[LA::addr(wr * WM + i * 16 + l15, kk + l4)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = Bs[LB::addr(wc * 32 + j * 16 + l15, kk + l4)];
+            for (int j = 0; j < NI; ++j) bf[j] = Bs[LB::addr(wc * WN + j * 16 + l15, kk + l4)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+    };
+
+    for (int kt = 0; kt < nk; kt += 2) {
+        slab_store<BM, !TA>(As, ra0);
+        slab_store<BN, TB>(Bs, rb0);
         __syncthreads();
+        if (kt + 2 < nk) {
+            slab_load<BM, !TA>(A, a.lda, m0, (kt + 2) * KT, a.M, a.K, a.vecA, ra0);
+            slab_load<BN, TB>(B, a.ldb, n0, (kt + 2) * KT, a.N, a.K, a.vecB, rb0);
+        }
+        compute();
+        __syncthreads();
+        if (kt + 1 < nk) {
+            slab_store<BM, !TA>(As, ra1);
+            slab_store<BN, TB>(Bs, rb1);
+            __syncthreads();
+            if (kt + 3 < nk) {
+                slab_load<BM, !TA>(A, a.lda, m0, (kt + 3) * KT, a.M, a.K, a.vecA, ra1);
+                slab_load<BN, TB>(B, a.ldb, n0, (kt + 3) * KT, a.N, a.K, a.vecB, rb1);
+            }
+            compute();
+            __syncthreads();
+        }
     }
 
     // C/D map of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 32 + j * 16 + l15;
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wc * WN + j * 16 + l15;
             if (col >= a.N) continue;
             const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wr * 32 + i * 16 + l4 * 4 + r;
+                const int row = m0 + wr * WM + i * 16 + l4 * 4 + r;
                 if (row >= a.M) continue;
                 float* cp = C + (long)row * a.ldc + col;
                 float v = a.alpha * acc[i][j][r] + bv;
@@ -167,36 +229,102 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmArgs a) {
         }
 }
 
-template <int BM, int BN>
-static void launch_tile(Seq& q, GemmArgs& a, int batch, bool tA, bool tB) {
-    const int tilesM = (a.M + BM - 1) / BM;
-    a.tilesN = (a.N + BN - 1) / BN;
-    dim3 grid(tilesM * a.tilesN, batch), block(256);
-    if (!tA && !tB)
-        hipLaunchKernelGGL((bgemm_kernel<BM, BN, false, false>), grid, block, 0, q.stream, a);
-    else if (!tA && tB)
-        hipLaunchKernelGGL((bgemm_kernel<BM, BN, false, true>), grid, block, 0, q.stream, a);
-    else if (tA && !tB)
-        hipLaunchKernelGGL((bgemm_kernel<BM, BN, true, false>), grid, block, 0, q.stream, a);
-    else
-        hipLaunchKernelGGL((bgemm_kernel<BM, BN, true, true>), grid, block, 0, q.stream, a);
+// One launch, up to GEMM_GROUP_MAX independent problems (same batch count): the workgroup finds its
+// problem from the tile prefix, then runs the body for that problem's transposes.
+struct GemmGroupArgs {
+    int count;
+    int tile0[GEMM_GROUP_MAX + 1];
+    GemmArgs p[GEMM_GROUP_MAX];
+};
+
+template <int R, bool KC>
+constexpr int lds_size() { return LdsImage<R, KC>::SIZE; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void bgemm_kernel(GemmGroupArgs g) {
+    __shared__ __attribute__((aligned(16))) float
+        lds[cmax(lds_size<BM, true>(), lds_size<BM, false>()) + cmax(lds_size<BN, true>(), lds_size<BN, false>()) + 8];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_GROUP_MAX; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.tile0[i]) pi = i;
+    const GemmArgs& a = g.p[pi];
+    const int tile = blockIdx.x - g.tile0[pi];
+    if (a.tA) {
+        if (a.tB) gemm_body<BM, BN, WAVES_M, WAVES_N, true, true>(a, tile, lds);
+        else gemm_body<BM, BN, WAVES_M, WAVES_N, true, false>(a, tile, lds);
+    } else {
+        if (a.tB) gemm_body<BM, BN, WAVES_M, WAVES_N, false, true>(a, tile, lds);
+        else gemm_body<BM, BN, WAVES_M, WAVES_N, false, false>(a, tile, lds);
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static void launch_tile(Seq& q, GemmGroupArgs& g, int batch) {
+    int total = 0;
+    for (int i = 0; i < g.count; ++i) {
+        GemmArgs& a = g.p[i];
+        a.tilesN = (a.N + BN - 1) / BN;
+        g.tile0[i] = total;
+        total += ((a.M + BM - 1) / BM) * a.tilesN;
+    }
+    g.tile0[g.count] = total;
+    hipLaunchKernelGGL((bgemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(total, batch), dim3(256), 0, q.stream, g);
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch) {
+    if (!q.ok() || batch <= 0 || count <= 0) return;
+    if (batch > 65535 || count > GEMM_GROUP_MAX) {
+        set_error("bgemm_group: batch %d / count %d out of range", batch, count);
+        q.err = DP_ERR_INVALID_ARG;
+        return;
+    }
+    GemmGroupArgs g{};
+    int maxN = 0;
+    for (int i = 0; i < count; ++i) {
+        const GemmDesc& s = d[i];
+        if (s.M <= 0 || s.N <= 0) continue;
+        GemmArgs& a = g.p[g.count++];
+        a = GemmArgs{s.A, s.B, s.C, s.bias, s.M, s.N, s.K, s.lda, s.ldb, s.ldc, s.sA, s.sB, s.sC, s.alpha, s.beta,
+                     s.act, 0, 0, 0, s.tA ? 1 : 0, s.tB ? 1 : 0};
+        a.vecA = aligned16(s.A) && (s.lda % 4 == 0) && (s.sA % 4 == 0);
+        a.vecB = aligned16(s.B) && (s.ldb % 4 == 0) && (s.sB % 4 == 0);
+        if (s.N > maxN) maxN = s.N;
+    }
+    if (g.count == 0) return;
+    // Largest tile that still gives >= TARGET workgroups (256 CUs x 2); smallest tile otherwise.
+    static const long TARGET = [] {
+        const char* e = getenv("DP_GEMM_TARGET_WGS");   // tuning knob: workgroups wanted before tiles grow
+        return e ? atol(e) : 512L;
+    }();
+    auto wgs = [&](int bm, int bn) {
+        long t = 0;
+        for (int i = 0; i < g.count; ++i)
+            t += (long)((g.p[i].M + bm - 1) / bm) * ((g.p[i].N + bn - 1) / bn) * batch;
+        return t;
+    };
+    if (maxN <= 16) {
+        launch_tile<64, 16, 4, 1>(q, g, batch);
+    } else if (maxN <= 32) {
+        if (wgs(128, 32) >= TARGET) launch_tile<128, 32, 4, 1>(q, g, batch);
+        else if (wgs(64, 32) >= TARGET) launch_tile<64, 32, 4, 1>(q, g, batch);
+        else launch_tile<32, 32, 2, 2>(q, g, batch);
+    } else {
+        if (wgs(64, 64) >= TARGET) launch_tile<64, 64, 2, 2>(q, g, batch);
+        else if (wgs(32, 64) >= TARGET) launch_tile<32, 64, 1, 4>(q, g, batch);
+        else launch_tile<16, 64, 1, 4>(q, g, batch);
+    }
+    q.check_launch("bgemm");
 }
 
 void bgemm(Seq& q, const float* A, const float* B, float* C, const float* bias, int batch, int M, int N,
            int K, int lda, int ldb, int ldc, long sA, long sB, long sC, bool tA, bool tB, float alpha,
            float beta, int act) {
-    if (!q.ok() || batch <= 0 || M <= 0 || N <= 0) return;
-    if (batch > 65535) {
-        set_error("bgemm: batch %d exceeds grid.y limit", batch);
-        q.err = DP_ERR_INVALID_ARG;
-        return;
-    }
-    GemmArgs a{A, B, C, bias, M, N, K, lda, ldb, ldc, sA, sB, sC, alpha, beta, act, 0};
-    if (N <= 32)
-        launch_tile<128, 32>(q, a, batch, tA, tB);
-    else
-        launch_tile<64, 64>(q, a, batch, tA, tB);
-    q.check_launch("bgemm");
+    GemmDesc d{A, B, C, bias, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, alpha, beta, act};
+    bgemm_group(q, &d, 1, batch);
 }
 
 }  // namespace dp

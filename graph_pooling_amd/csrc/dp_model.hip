@@ -81,7 +81,7 @@ struct LevelSave {
     float* Za;
     LayerSave layer[DP_MAX_LAYERS];
     float* S;
-    float* T;
+    float* T;     // Tt = A^T S, [B, n, K]
     float* Xn;
     float* An;
     int* argmax;
@@ -198,11 +198,12 @@ struct LevelIO {
     const float* adj;  // [B, n, n]
 };
 
-// P = [x_e W_e | x_a W_a]  for layer l of level li
+// P = [x_e W_e | x_a W_a]  for layer l of level li  (one grouped launch)
 void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
                const float* params, int l, float* Pj) {
     const int ct = li.ctot[l];
     const int B = c.B, n = li.n;
+    GemmDesc d[2];
     for (int g = 0; g < li.G; ++g) {
         const dp_stack_cfg* st = g == 0 ? li.e : li.a;
         const int din = st->dims[l], dout = st->dims[l + 1];
@@ -216,9 +217,10 @@ void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const Level
             ldin = g == 0 ? li.D : li.Da;
         }
         const int c0 = g == 0 ? 0 : li.e->dims[l + 1];
-        bgemm(q, xin, PW(params, st->w_off[l]), Pj + c0, nullptr, B, n, dout, din, ldin, dout, ct, (long)n * ldin,
-              0, (long)n * ct, false, false, 1.f, 0.f, 0);
+        d[g] = GemmDesc{xin, PW(params, st->w_off[l]), Pj + c0, nullptr, n, dout, din, ldin, dout, ct,
+                        (long)n * ldin, 0, (long)n * ct, false, false, 1.f, 0.f, 0};
     }
+    bgemm_group(q, d, li.G, B);
 }
 
 void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
@@ -230,8 +232,6 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
         const int ct = li.ctot[l];
         const bool last = l == li.L - 1;
         transform(q, c, li, lv, io, params, l, Pj);
-        bgemm(q, io.adj, Pj, Uj, nullptr, B, n, ct, n, n, ct, ct, (long)n * n, (long)n * ct, (long)n * ct, false,
-              false, 1.f, 0.f, 0);
         RowGroups g = groups_of(li, l);
         GroupCPtrs bias{};
         bias.p[0] = PW(params, li.e->b_off[l]);
@@ -249,16 +249,21 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
             yout.ld[1] = ct;
         }
         const int stats_mode = (!last && bn) ? 1 : 0;
-        rownorm_fwd(q, Uj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn, stats_mode ? part : nullptr,
-                    (long)B * n, 1, stats_mode);
+        // aggregation + GraphConv tail in one launch when the panel kernel takes the shape
+        if (!aggregate_rownorm_fwd(q, io.adj, Pj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn,
+                                   stats_mode ? part : nullptr, B, n, 1, stats_mode)) {
+            bgemm(q, io.adj, Pj, Uj, nullptr, B, n, ct, n, n, ct, ct, (long)n * n, (long)n * ct, (long)n * ct, false,
+                  false, 1.f, 0.f, 0);
+            rownorm_fwd(q, Uj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn,
+                        stats_mode ? part : nullptr, (long)B * n, 1, stats_mode);
+        }
         if (!last) {
-            if (bn) bn_finalize(q, part, lv.layer[l].stats, B, n, g);
             GroupPtrs xout{};
             xout.p[0] = lv.Ze + li.coff_e[l];
             xout.ld[0] = li.D;
             xout.p[1] = li.a ? lv.Za + li.coff_a[l] : nullptr;
             xout.ld[1] = li.Da;
-            bn_apply_fwd(q, lv.layer[l].Y, ct, bn ? lv.layer[l].stats : nullptr, g, xout, B, n, 1);
+            bn_apply_fwd(q, lv.layer[l].Y, ct, bn ? part : nullptr, lv.layer[l].stats, g, xout, B, n, 1);
         }
     }
 }
@@ -272,7 +277,7 @@ struct LevelGrad {
 
 void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
                     const float* params, const LevelGrad& gr, float* slabs, long slab_stride, float* Pj, float* dUj,
-                    float* Gj, float* part, float* means) {
+                    float* Gj, float* part, float* const* bpart, BiasReduceTable& btab) {
     const int B = c.B, n = li.n;
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
@@ -300,49 +305,58 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
             y.ld[1] = ct;
         }
         const bool has_bn = !last && bn;
-        if (has_bn) {
-            bn_bwd_partials(q, dx, xhat, g, part, (long)B * n);
-            sum_finalize(q, part, means, B, n, g);
-        }
-        rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, means, g, dUj, ct, B, n, !last, has_bn, 1);
-        // bias gradients (per-graph column sums into the slabs)
+        if (has_bn) bn_bwd_partials(q, dx, xhat, g, part, (long)B * n);
+        rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, part, g, dUj, ct, bpart[l], B, n, !last,
+                    has_bn, 1);
+        // bias gradients: per-(graph, chunk) column sums of dU, reduced once at the end of the backward
         for (int gi = 0; gi < li.G; ++gi) {
             const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
-            if (st->b_off[l] >= 0)
-                colsum_batched(q, dUj + g.c0[gi], ct, (long)n * ct, n, g.w[gi], slabs + st->b_off[l], slab_stride, B);
+            if (st->b_off[l] >= 0 && btab.count < BIAS_TABLE_MAX)
+                btab.e[btab.count++] = BiasReduceEntry{bpart[l], B * rownorm_bwd_chunks(n), ct, g.c0[gi], g.w[gi],
+                                                       st->b_off[l]};
         }
         // G = A^T dU (+ dU)
-        bgemm(q, io.adj, dUj, Gj, nullptr, B, n, ct, n, n, ct, ct, (long)n * n, (long)n * ct, (long)n * ct, true, false,
-              1.f, 0.f, 0);
+        aggregate(q, io.adj, dUj, ct, Gj, ct, B, n, ct, true, 0.f);
         if (add_self) axpy(q, Gj, dUj, 1.f, (long)B * n * ct);
-        for (int gi = 0; gi < li.G; ++gi) {
-            const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
-            const int din = st->dims[l], dout = st->dims[l + 1];
-            const float* xin;
-            int ldin;
-            if (l == 0) {
-                xin = gi == 0 ? io.x0e : io.x0a;
-                ldin = din;
-            } else {
-                xin = gi == 0 ? lv.Ze + li.coff_e[l - 1] : lv.Za + li.coff_a[l - 1];
-                ldin = gi == 0 ? li.D : li.Da;
+        {
+            GemmDesc d[4];
+            int nd = 0;
+            for (int gi = 0; gi < li.G; ++gi) {
+                const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
+                const int din = st->dims[l], dout = st->dims[l + 1];
+                const float* xin;
+                int ldin;
+                if (l == 0) {
+                    xin = gi == 0 ? io.x0e : io.x0a;
+                    ldin = din;
+                } else {
+                    xin = gi == 0 ? lv.Ze + li.coff_e[l - 1] : lv.Za + li.coff_a[l - 1];
+                    ldin = gi == 0 ? li.D : li.Da;
+                }
+                // dW slab[b] = x_in[b]^T G[b]
+                d[nd++] = GemmDesc{xin, Gj + g.c0[gi], slabs + st->w_off[l], nullptr, din, dout, n, ldin, ct, dout,
+                                   (long)n * ldin, (long)n * ct, slab_stride, true, false, 1.f, 0.f, 0};
+                // gradient w.r.t. the layer input: G W^T (accumulated into the concat-gradient slice)
+                float* dxin = nullptr;
+                int lddx = 0;
+                if (l > 0) {
+                    dxin = gi == 0 ? gr.dZe + li.coff_e[l - 1] : gr.dZa + li.coff_a[l - 1];
+                    lddx = gi == 0 ? li.D : li.Da;
+                } else if (gr.dX0 && gi == 0) {
+                    dxin = gr.dX0;
+                    lddx = din;
+                }
+                if (dxin)
+                    d[nd++] = GemmDesc{Gj + g.c0[gi], PW(params, st->w_off[l]), dxin, nullptr, n, din, dout, ct, dout,
+                                       lddx, (long)n * ct, 0, (long)n * lddx, false, true, 1.f, 1.f, 0};
             }
-            // dW slab[b] = x_in[b]^T G[b]
-            bgemm(q, xin, Gj + g.c0[gi], slabs + st->w_off[l], nullptr, B, din, dout, n, ldin, ct, dout,
-                  (long)n * ldin, (long)n * ct, slab_stride, true, false, 1.f, 0.f, 0);
-            // gradient w.r.t. the layer input: G W^T
-            float* dxin = nullptr;
-            int lddx = 0;
-            if (l > 0) {
-                dxin = gi == 0 ? gr.dZe + li.coff_e[l - 1] : gr.dZa + li.coff_a[l - 1];
-                lddx = gi == 0 ? li.D : li.Da;
-            } else if (gr.dX0) {
-                dxin = gr.dX0;
-                lddx = din;
+            bgemm_group(q, d, nd, B);
+            // both stacks of a pooled level read the same input X_j: the assign stack's share is added after
+            if (l == 0 && gr.dX0 && li.G == 2) {
+                const dp_stack_cfg* st = li.a;
+                bgemm(q, Gj + g.c0[1], PW(params, st->w_off[0]), gr.dX0, nullptr, B, n, st->dims[0], st->dims[1], ct,
+                      st->dims[1], st->dims[0], (long)n * ct, 0, (long)n * st->dims[0], false, true, 1.f, 1.f, 0);
             }
-            if (dxin)
-                bgemm(q, Gj + g.c0[gi], PW(params, st->w_off[l]), dxin, nullptr, B, n, din, dout, ct, dout, lddx,
-                      (long)n * ct, 0, (long)n * lddx, false, true, 1.f, 1.f, 0);
         }
         if (gr.dAdj) {
             // dA += dU P^T   (P = X W recomputed)
@@ -414,11 +428,11 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
             softmax_mask_fwd(q, sc.logits, K, lv.S, K, nn_j, B, n, K);
             if (j == 0 && assign_out) q.copy(assign_out, lv.S, (size_t)B * n * K * sizeof(float));
             // X' = S^T Z ; T = S^T A ; A' = T S
+            // X' = S^T Z ;  Tt = A^T S  (= (S^T A)^T, [n x K]) ;  A' = Tt^T S
             bgemm(q, lv.S, lv.Ze, lv.Xn, nullptr, B, K, li.D, n, K, li.D, li.D, (long)n * K, (long)n * li.D,
                   (long)K * li.D, true, false, 1.f, 0.f, 0);
-            bgemm(q, lv.S, io.adj, lv.T, nullptr, B, K, n, n, K, n, n, (long)n * K, (long)n * n, (long)K * n, true, false,
-                  1.f, 0.f, 0);
-            bgemm(q, lv.T, lv.S, lv.An, nullptr, B, K, K, n, n, K, K, (long)K * n, (long)n * K, (long)K * K, false, false,
+            aggregate(q, io.adj, lv.S, K, lv.T, K, B, n, K, true, 0.f);
+            bgemm(q, lv.T, lv.S, lv.An, nullptr, B, K, K, n, K, K, K, (long)n * K, (long)n * K, (long)K * K, true, false,
                   1.f, 0.f, 0);
         }
     }
@@ -441,6 +455,17 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     // ---- workspace walk
     size_t maxPU = 0, maxPart = 0, maxSK = 0, maxMeans = 0;
     LevelGrad gr[DP_MAX_LEVELS + 1]{};
+    float* bpart[DP_MAX_LEVELS + 1][DP_MAX_LAYERS];
+    // zero-initialised gradient accumulators are carved from ONE block (one memset)
+    const size_t zero_begin = q.ws_off;
+    for (int j = 0; j <= P; ++j) {
+        const LevelInfo li = level_info(c, j);
+        const size_t rows = (size_t)B * li.n;
+        gr[j].dZe = q.alloc<float>(rows * li.D);
+        gr[j].dX0 = j >= 1 ? q.alloc<float>(rows * li.e->dims[0]) : nullptr;
+        gr[j].dAdj = j >= 1 ? q.alloc<float>(rows * li.n) : nullptr;
+    }
+    const size_t zero_end = q.ws_off;
     for (int j = 0; j <= P; ++j) {
         const LevelInfo li = level_info(c, j);
         const size_t rows = (size_t)B * li.n;
@@ -448,22 +473,23 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
         if (rows * li.G * 2 > maxPart) maxPart = rows * li.G * 2;
         if ((size_t)li.n * li.G * 2 > maxMeans) maxMeans = (size_t)li.n * li.G * 2;
         if (li.a && rows * li.K > maxSK) maxSK = rows * li.K;
-        gr[j].dZe = q.alloc<float>(rows * li.D);
         gr[j].dZa = li.a ? q.alloc<float>(rows * li.Da) : nullptr;
-        gr[j].dX0 = j >= 1 ? q.alloc<float>(rows * li.e->dims[0]) : nullptr;
-        gr[j].dAdj = j >= 1 ? q.alloc<float>(rows * li.n) : nullptr;
+        for (int l = 0; l < li.L; ++l)
+            bpart[j][l] = q.alloc<float>((size_t)B * rownorm_bwd_chunks(li.n) * li.ctot[l]);
     }
+    BiasReduceTable btab{};
     float* Pj = q.alloc<float>(maxPU);
     float* dUj = q.alloc<float>(maxPU);
     float* Gj = q.alloc<float>(maxPU);
     float* part = q.alloc<float>(maxPart);
-    float* means = q.alloc<float>(maxMeans);
     float* dS = q.alloc<float>(maxSK ? maxSK : 1);
     float* dlog = q.alloc<float>(maxSK ? maxSK : 1);
     float* V = q.alloc<float>(maxSK ? maxSK : 1);
+    float* V2 = q.alloc<float>(maxSK ? maxSK : 1);
     float* slabs = q.alloc<float>((size_t)B * (c.n_graph_params > 0 ? c.n_graph_params : 1));
     float* dh[DP_MAX_PRED + 2];
-    for (int i = 0; i <= c.n_pred; ++i) dh[i] = q.alloc<float>((size_t)B * c.pred_dims[i]);
+    for (int i = 0; i < c.n_pred; ++i) dh[i] = q.alloc<float>((size_t)B * c.pred_dims[i]);
+    dh[c.n_pred] = const_cast<float*>(d_ypred);   // read only
     float* dZm = nullptr;
     if (c.readout == 1) {
         const LevelInfo li = level_info(c, 0);
@@ -472,16 +498,21 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     if (q.err) return q.err;
     const long slab_stride = c.n_graph_params;
 
-    q.zero(grads, (size_t)c.n_params * sizeof(float));
+    // every entry of `grads` is written below (weights: slab reduce / direct GEMM; biases: reduce_bias /
+    // column sums), so no memset of it is needed
+    q.zero(q.ws + zero_begin, zero_end - zero_begin);
     // ---- pred_model backward
-    q.copy(dh[c.n_pred], d_ypred, (size_t)B * c.pred_dims[c.n_pred] * sizeof(float));
     for (int i = c.n_pred - 1; i >= 0; --i) {
         const int din = c.pred_dims[i], dout = c.pred_dims[i + 1];
-        bgemm(q, dh[i + 1], sv.hid[i], grads + c.pred_w_off[i], nullptr, 1, dout, din, B, dout, din, din, 0, 0, 0, true,
-              false, 1.f, 0.f, 0);
+        {
+            GemmDesc d[2] = {
+                {dh[i + 1], sv.hid[i], grads + c.pred_w_off[i], nullptr, dout, din, B, dout, din, din, 0, 0, 0, true,
+                 false, 1.f, 0.f, 0},
+                {dh[i + 1], PW(params, c.pred_w_off[i]), dh[i], nullptr, B, din, dout, dout, din, din, 0, 0, 0, false,
+                 false, 1.f, 0.f, 0}};
+            bgemm_group(q, d, 2, 1);
+        }
         if (c.pred_b_off[i] >= 0) colsum_batched(q, dh[i + 1], dout, 0, B, dout, grads + c.pred_b_off[i], 0, 1);
-        bgemm(q, dh[i + 1], PW(params, c.pred_w_off[i]), dh[i], nullptr, 1, B, din, dout, dout, din, din, 0, 0, 0, false,
-              false, 1.f, 0.f, 0);
         if (i > 0) relu_bwd_inplace(q, dh[i], sv.hid[i], (long)B * din);
     }
     const float* dfeat = dh[0];
@@ -490,9 +521,6 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     int featoff = 0;
     for (int j = 0; j <= P; ++j) {
         const LevelInfo li = level_info(c, j);
-        q.zero(gr[j].dZe, (size_t)B * li.n * li.D * sizeof(float));
-        if (gr[j].dX0) q.zero(gr[j].dX0, (size_t)B * li.n * li.e->dims[0] * sizeof(float));
-        if (gr[j].dAdj) q.zero(gr[j].dAdj, (size_t)B * li.n * li.n * sizeof(float));
         if (c.readout == 0) {
             const int rw = readout_width(c, li);
             float* dz = (c.flags & DP_F_LAST_ONLY) ? gr[j].dZe + li.coff_e[li.L - 1] : gr[j].dZe;
@@ -519,38 +547,44 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
             const int K = li.K, D = li.D;
             const float* dXn = gr[j + 1].dX0;
             const float* dAn = gr[j + 1].dAdj;
-            // X' = S^T Z
-            bgemm(q, lv.S, dXn, gr[j].dZe, nullptr, B, n, D, K, K, D, D, (long)n * K, (long)K * D, (long)n * D, false,
-                  false, 1.f, 1.f, 0);
-            bgemm(q, lv.Ze, dXn, dS, nullptr, B, n, K, D, D, D, K, (long)n * D, (long)K * D, (long)n * K, false, true,
-                  1.f, 0.f, 0);
-            // A' = T S, T = S^T A
-            bgemm(q, lv.T, dAn, dS, nullptr, B, n, K, K, n, K, K, (long)K * n, (long)K * K, (long)n * K, true, false, 1.f,
-                  1.f, 0);
-            bgemm(q, lv.S, dAn, V, nullptr, B, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, true, 1.f,
-                  0.f, 0);
-            bgemm(q, io.adj, V, dS, nullptr, B, n, K, n, n, K, K, (long)n * n, (long)n * K, (long)n * K, false, false,
-                  1.f, 1.f, 0);
-            if (gr[j].dAdj) {
-                // dA_j += S dA' S^T
-                bgemm(q, lv.S, dAn, V, nullptr, B, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, false,
-                      1.f, 0.f, 0);
-                bgemm(q, V, lv.S, gr[j].dAdj, nullptr, B, n, n, K, K, K, n, (long)n * K, (long)n * K, (long)n * n, false,
-                      true, 1.f, 1.f, 0);
+            {
+                // X' = S^T Z:  dZ += S dX',  dS = Z dX'^T ;  A' = (S^T A) S:  V = S dA'^T,  W = S dA'
+                GemmDesc d[4] = {
+                    {lv.S, dXn, gr[j].dZe, nullptr, n, D, K, K, D, D, (long)n * K, (long)K * D, (long)n * D, false, false,
+                     1.f, 1.f, 0},
+                    {lv.Ze, dXn, dS, nullptr, n, K, D, D, D, K, (long)n * D, (long)K * D, (long)n * K, false, true, 1.f,
+                     0.f, 0},
+                    {lv.S, dAn, V, nullptr, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, true, 1.f, 0.f,
+                     0},
+                    {lv.S, dAn, V2, nullptr, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, false, 1.f,
+                     0.f, 0}};
+                bgemm_group(q, d, gr[j].dAdj ? 4 : 3, B);
             }
+            // dS += T^T dA' ;  dS += A V
+            bgemm(q, lv.T, dAn, dS, nullptr, B, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, false, 1.f,
+                  1.f, 0);
+            aggregate(q, io.adj, V, K, dS, K, B, n, K, false, 1.f);
+            if (gr[j].dAdj)   // dA_j += (S dA') S^T
+                bgemm(q, V2, lv.S, gr[j].dAdj, nullptr, B, n, n, K, K, K, n, (long)n * K, (long)n * K, (long)n * n, false,
+                      true, 1.f, 1.f, 0);
             if (j == 0 && d_assign) axpy(q, dS, d_assign, 1.f, (long)B * n * K);
             softmax_mask_bwd(q, lv.S, K, dS, K, j == 0 ? num_nodes : nullptr, dlog, K, B, n, K);
             // assign_pred: logits = Za Wp^T + bp
-            bgemm(q, dlog, lv.Za, slabs + c.assign_pred_w_off[j], nullptr, B, K, li.Da, n, K, li.Da, li.Da, (long)n * K,
-                  (long)n * li.Da, slab_stride, true, false, 1.f, 0.f, 0);
+            {
+                GemmDesc d[2] = {
+                    {dlog, lv.Za, slabs + c.assign_pred_w_off[j], nullptr, K, li.Da, n, K, li.Da, li.Da, (long)n * K,
+                     (long)n * li.Da, slab_stride, true, false, 1.f, 0.f, 0},
+                    {dlog, PW(params, c.assign_pred_w_off[j]), gr[j].dZa, nullptr, n, li.Da, K, K, li.Da, li.Da,
+                     (long)n * K, 0, (long)n * li.Da, false, false, 1.f, 0.f, 0}};
+                bgemm_group(q, d, 2, B);
+            }
             if (c.assign_pred_b_off[j] >= 0)
                 colsum_batched(q, dlog, K, (long)n * K, n, K, slabs + c.assign_pred_b_off[j], slab_stride, B);
-            bgemm(q, dlog, PW(params, c.assign_pred_w_off[j]), gr[j].dZa, nullptr, B, n, li.Da, K, K, li.Da, li.Da,
-                  (long)n * K, 0, (long)n * li.Da, false, false, 1.f, 0.f, 0);
         }
-        level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, Pj, dUj, Gj, part, means);
+        level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, Pj, dUj, Gj, part, bpart[j], btab);
     }
     reduce_slabs(q, slabs, slab_stride, B, grads, c.n_graph_params, 0);
+    reduce_bias(q, btab, grads);
     return q.err;
 }
 

@@ -109,96 +109,63 @@ void rownorm_fwd(Seq& q, const float* U, int ldu, const float* P, GroupCPtrs bia
     q.check_launch("rownorm_fwd");
 }
 
-// ------------------------------------------------------------------ bn finalize
-// part[b, n, g, {mean, M2}] -> stats[n, g, {mu, rstd}]  (apply_bn, encoders.py:1048-1052:
-// per node index n, statistics over (batch, feature), biased variance, eps 1e-5).
-__global__ void k_bn_finalize(const float* part, float* stats, int B, int n, RowGroups g) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * g.G) return;
-    const int node = i / g.G, gi = i % g.G;
-    const double w = (double)g.w[gi];
-    double sm = 0.0, sm2 = 0.0;
-    for (int b = 0; b < B; ++b) sm += (double)part[(((long)b * n + node) * g.G + gi) * 2];
-    const double mu = sm / (double)B;
-    for (int b = 0; b < B; ++b) {
-        const float* p = part + (((long)b * n + node) * g.G + gi) * 2;
-        const double d = (double)p[0] - mu;
-        sm2 += (double)p[1] + w * d * d;
-    }
-    const double var = sm2 / ((double)B * w);
-    stats[i * 2 + 0] = (float)mu;
-    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)BN_EPS));
-}
-
-void bn_finalize(Seq& q, const float* part, float* stats, int B, int n, RowGroups g) {
-    if (!q.ok()) return;
-    const int items = n * g.G;
-    hipLaunchKernelGGL(k_bn_finalize, dim3((items + 255) / 256), dim3(256), 0, q.stream, part, stats, B, n, g);
-    q.check_launch("bn_finalize");
-}
-
-// part[b, n, g, {s0, s1}] -> means[n, g, {s0, s1}] / (B * w)   (BN backward reductions)
-__global__ void k_sum_finalize(const float* part, float* means, int B, int n, RowGroups g) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * g.G) return;
-    const int node = i / g.G, gi = i % g.G;
-    double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const float* p = part + (((long)b * n + node) * g.G + gi) * 2;
-        s0 += (double)p[0];
-        s1 += (double)p[1];
-    }
-    const double cnt = (double)B * (double)g.w[gi];
-    means[i * 2 + 0] = (float)(s0 / cnt);
-    means[i * 2 + 1] = (float)(s1 / cnt);
-}
-
-void sum_finalize(Seq& q, const float* part, float* means, int B, int n, RowGroups g) {
-    if (!q.ok()) return;
-    const int items = n * g.G;
-    hipLaunchKernelGGL(k_sum_finalize, dim3((items + 255) / 256), dim3(256), 0, q.stream, part, means, B, n, g);
-    q.check_launch("sum_finalize");
-}
-
 // ------------------------------------------------------------------ bn apply fwd
-// x = (relu(y) - mu_n) * rstd_n  (or relu(y) when stats == null), written into the concat buffer.
+// apply_bn (encoders.py:1048-1052): per node index n, statistics over (batch, feature), biased variance,
+// eps 1e-5.  Each row team combines the B per-row partials (row mean, row M2) of its node index itself
+// (Chan's parallel variance), so no separate finalize launch is needed; the b == 0 team stores
+// (mu, rstd) for the backward pass.  x = (relu(y) - mu_n) * rstd_n, written into the concat buffer.
 struct BnApplyArgs {
     const float* Y;
     int ldy;
-    const float* stats;
+    const float* part;   // [B, n, G, 2] or null (no BN)
+    float* stats;        // [n, G, 2] out
     RowGroups g;
     GroupPtrs xout;
-    long rows;
-    int n;
+    int B, n;
     int relu;
 };
 __global__ __launch_bounds__(256) void k_bn_apply_fwd(BnApplyArgs a) {
     const int tl = threadIdx.x & 15;
     const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const long nteams = (long)gridDim.x * 16;
-    const long items = a.rows * a.g.G;
+    const long items = (long)a.B * a.n * a.g.G;
     for (long it = team; it < items; it += nteams) {
         const long row = it / a.g.G;
         const int g = (int)(it % a.g.G);
         const int node = (int)(row % a.n);
+        const int w = a.g.w[g];
         float mu = 0.f, rstd = 1.f;
-        if (a.stats) {
-            mu = a.stats[((long)node * a.g.G + g) * 2];
-            rstd = a.stats[((long)node * a.g.G + g) * 2 + 1];
+        if (a.part) {
+            const long pstride = (long)a.n * a.g.G * 2;
+            const float* p = a.part + ((long)node * a.g.G + g) * 2;
+            float sm = 0.f;
+            for (int b = tl; b < a.B; b += 16) sm += p[b * pstride];
+            mu = team_sum(sm) / (float)a.B;
+            float s2 = 0.f;
+            for (int b = tl; b < a.B; b += 16) {
+                const float d = p[b * pstride] - mu;
+                s2 += p[b * pstride + 1] + (float)w * d * d;
+            }
+            const float var = team_sum(s2) / ((float)a.B * (float)w);
+            rstd = 1.0f / sqrtf(var + BN_EPS);
+            if (row < a.n && tl == 0) {   // the b == 0 row of this node
+                a.stats[((long)node * a.g.G + g) * 2] = mu;
+                a.stats[((long)node * a.g.G + g) * 2 + 1] = rstd;
+            }
         }
         const float* y = a.Y + row * a.ldy + a.g.c0[g];
         float* x = a.xout.p[g] + row * a.xout.ld[g];
-        for (int c = tl; c < a.g.w[g]; c += 16) {
+        for (int c = tl; c < w; c += 16) {
             const float v = a.relu ? fmaxf(y[c], 0.f) : y[c];
             x[c] = (v - mu) * rstd;
         }
     }
 }
-void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* stats, RowGroups g, GroupPtrs xout, int B,
-                  int n, int relu) {
+void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* part, float* stats, RowGroups g, GroupPtrs xout,
+                  int B, int n, int relu) {
     if (!q.ok()) return;
-    BnApplyArgs a{Y, ldy, stats, g, xout, (long)B * n, n, relu};
-    hipLaunchKernelGGL(k_bn_apply_fwd, dim3(team_grid(a.rows * g.G)), dim3(256), 0, q.stream, a);
+    BnApplyArgs a{Y, ldy, part, stats, g, xout, B, n, relu};
+    hipLaunchKernelGGL(k_bn_apply_fwd, dim3(team_grid((long)B * n * g.G)), dim3(256), 0, q.stream, a);
     q.check_launch("bn_apply_fwd");
 }
 
@@ -249,23 +216,36 @@ struct RownormBwdArgs {
     GroupCPtrs dx, xhat, y;
     const float* invn;
     const float* stats;
-    const float* means;
+    const float* part2;   // [B, n, G, 2] per-row (sum dx, sum dx*xhat)
     RowGroups g;
     float* dU;
     int ldu;
-    long rows;
-    int n;
+    float* bpart;         // [B, chunks, ldu] column sums of dU per (graph, row chunk) or null
+    int B, n;
+    int rows_per_chunk;
     int has_relu, has_bn, normalize;
 };
+// grid (chunks, B): a workgroup owns a contiguous chunk of rows of ONE graph, so the column sums of dU
+// (the bias gradients, db = sum_rows dU) can be accumulated in LDS and leave as one partial per workgroup.
 __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float colsum[];
     const int tl = threadIdx.x & 15;
-    const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const long nteams = (long)gridDim.x * 16;
-    const long items = a.rows * a.g.G;
-    for (long it = team; it < items; it += nteams) {
-        const long row = it / a.g.G;
-        const int g = (int)(it % a.g.G);
-        const int node = (int)(row % a.n);
+    const int team = threadIdx.x >> 4;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int ct = a.g.c0[a.g.G - 1] + a.g.w[a.g.G - 1];
+    // each 16-lane team owns one row of the LDS accumulator (no atomics: lane c owns columns c, c+16, ...)
+    float* mysum = colsum + team * ct;
+    if (a.bpart) {
+        for (int c = threadIdx.x; c < 16 * ct; c += 256) colsum[c] = 0.f;
+        __syncthreads();
+    }
+    const int r0 = chunk * a.rows_per_chunk;
+    const int r1 = min(a.n, r0 + a.rows_per_chunk);
+    const int items = (r1 - r0) * a.g.G;
+    for (int it = team; it < items; it += 16) {
+        const int node = r0 + it / a.g.G;
+        const int g = it % a.g.G;
+        const long row = (long)b * a.n + node;
         const int w = a.g.w[g];
         const float* dx = a.dx.p[g] + row * a.dx.ld[g];
         const float* y = a.y.p[g] + row * a.y.ld[g];
@@ -273,10 +253,18 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
         float rstd = 1.f, m0 = 0.f, m1 = 0.f;
         if (a.has_bn) {
             rstd = a.stats[((long)node * a.g.G + g) * 2 + 1];
-            m0 = a.means[((long)node * a.g.G + g) * 2];
-            m1 = a.means[((long)node * a.g.G + g) * 2 + 1];
+            const long pstride = (long)a.n * a.g.G * 2;
+            const float* p = a.part2 + ((long)node * a.g.G + g) * 2;
+            float s0 = 0.f, s1 = 0.f;
+            for (int bb = tl; bb < a.B; bb += 16) {
+                s0 += p[bb * pstride];
+                s1 += p[bb * pstride + 1];
+            }
+            const float cnt = (float)a.B * (float)w;
+            m0 = team_sum(s0) / cnt;
+            m1 = team_sum(s1) / cnt;
         }
-        const float inv = a.normalize ? a.invn[it] : 1.f;
+        const float inv = a.normalize ? a.invn[row * a.g.G + g] : 1.f;
         const bool project = a.normalize && (inv < 1.0f / L2_EPS);
         float dot = 0.f;
         for (int c = tl; c < w; c += 16) {
@@ -293,40 +281,87 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
             const float yy = y[c];
             if (a.has_bn) d = rstd * (d - m0 - xh[c] * m1);
             if (a.has_relu) d = yy > 0.f ? d : 0.f;
-            du[c] = project ? inv * (d - yy * dot) : inv * d;
+            const float v = project ? inv * (d - yy * dot) : inv * d;
+            du[c] = v;
+            if (a.bpart) mysum[a.g.c0[g] + c] += v;
+        }
+    }
+    if (a.bpart) {
+        __syncthreads();
+        float* out = a.bpart + ((long)b * gridDim.x + chunk) * a.ldu;
+        for (int c = threadIdx.x; c < ct; c += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += colsum[k * ct + c];
+            out[c] = t;
         }
     }
 }
+int rownorm_bwd_chunks(int n) { return (n + 31) / 32; }
 void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const float* invn, const float* stats,
-                 const float* means, RowGroups g, float* dU, int ldu, int B, int n, int has_relu, int has_bn,
-                 int normalize) {
+                 const float* part2, RowGroups g, float* dU, int ldu, float* bpart, int B, int n, int has_relu,
+                 int has_bn, int normalize) {
     if (!q.ok()) return;
-    RownormBwdArgs a{dx, xhat, y, invn, stats, means, g, dU, ldu, (long)B * n, n, has_relu, has_bn, normalize};
-    hipLaunchKernelGGL(k_rownorm_bwd, dim3(team_grid(a.rows * g.G)), dim3(256), 0, q.stream, a);
+    RownormBwdArgs a{dx, xhat, y, invn, stats, part2, g, dU, ldu, bpart, B, n, 32, has_relu, has_bn, normalize};
+    const int ct = g.c0[g.G - 1] + g.w[g.G - 1];
+    hipLaunchKernelGGL(k_rownorm_bwd, dim3(rownorm_bwd_chunks(n), B), dim3(256),
+                       bpart ? 16 * ct * sizeof(float) : 0, q.stream, a);
     q.check_launch("rownorm_bwd");
+}
+
+// Bias gradients: grads[dst + c] = sum over (graph, chunk) rows of bpart[., c0 + c]   (one launch for all layers)
+__global__ __launch_bounds__(1024) void k_reduce_bias(BiasReduceTable t, float* grads) {
+    __shared__ float red[16][64];
+    const BiasReduceEntry& e = t.e[blockIdx.x];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    if (blockIdx.y * 64 >= e.w) return;
+    float s = 0.f;
+    if (c < e.w)
+        for (int r = rl; r < e.rows; r += 16) s += e.src[(long)r * e.ld + e.c0 + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < e.w) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][cl];
+        grads[e.dst + c] = v;
+    }
+}
+void reduce_bias(Seq& q, const BiasReduceTable& t, float* grads) {
+    if (!q.ok() || t.count <= 0) return;
+    int maxw = 1;
+    for (int i = 0; i < t.count; ++i) maxw = t.e[i].w > maxw ? t.e[i].w : maxw;
+    hipLaunchKernelGGL(k_reduce_bias, dim3(t.count, (maxw + 63) / 64), dim3(1024), 0, q.stream, t, grads);
+    q.check_launch("reduce_bias");
 }
 
 // ------------------------------------------------------------------ column sums
 // out[b, c] = sum_r X[b, r, c]    (bias gradients; deterministic)
-__global__ __launch_bounds__(256) void k_colsum_batched(const float* X, int ldx, long strideX, int rows, int cols,
-                                                        float* out, long strideOut) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void k_colsum_batched(const float* X, int ldx, long strideX, int rows, int cols,
+                                                         float* out, long strideOut) {
+    __shared__ float red[16][64];
     const int b = blockIdx.y;
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
     if (c < cols) {
         const float* x = X + (long)b * strideX + c;
-        for (int r = rl; r < rows; r += 4) s += x[(long)r * ldx];
+        for (int r = rl; r < rows; r += 16) s += x[(long)r * ldx];
     }
     red[rl][cl] = s;
     __syncthreads();
-    if (rl == 0 && c < cols) out[(long)b * strideOut + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (rl == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        out[(long)b * strideOut + c] = t;
+    }
 }
 void colsum_batched(Seq& q, const float* X, int ldx, long strideX, int rows, int cols, float* out, long strideOut,
                     int batch) {
     if (!q.ok() || cols <= 0 || batch <= 0) return;
-    hipLaunchKernelGGL(k_colsum_batched, dim3((cols + 63) / 64, batch), dim3(256), 0, q.stream, X, ldx, strideX,
+    hipLaunchKernelGGL(k_colsum_batched, dim3((cols + 63) / 64, batch), dim3(1024), 0, q.stream, X, ldx, strideX,
                        rows, cols, out, strideOut);
     q.check_launch("colsum_batched");
 }
@@ -395,10 +430,10 @@ void softmax_mask_bwd(Seq& q, const float* S, int lds, const float* dS, int ldds
 // ------------------------------------------------------------------ masked max readout
 // out[b, f] = max_n (n < n_b ? Z[b, n, f] : 0)   (max over Z * mask, encoders.py:1079-1080,1257).
 // Ties -> lowest row index (torch CPU max).  argmax = -1 when the winner is a masked (zero) row.
-__global__ __launch_bounds__(256) void k_masked_max_fwd(const float* Z, int ldz, const int* num_nodes, float* out,
-                                                        int ldo, int* argmax, int lda, int n, int F) {
-    __shared__ float sv[4][64];
-    __shared__ int si[4][64];
+__global__ __launch_bounds__(1024) void k_masked_max_fwd(const float* Z, int ldz, const int* num_nodes, float* out,
+                                                         int ldo, int* argmax, int lda, int n, int F) {
+    __shared__ float sv[16][64];
+    __shared__ int si[16][64];
     const int b = blockIdx.y;
     const int fl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int f = blockIdx.x * 64 + fl;
@@ -407,7 +442,7 @@ __global__ __launch_bounds__(256) void k_masked_max_fwd(const float* Z, int ldz,
     int bi = -1;
     if (f < F) {
         const float* z = Z + (long)b * n * ldz + f;
-        for (int r = rl; r < nb; r += 4) {
+        for (int r = rl; r < nb; r += 16) {
             const float v = z[(long)r * ldz];
             if (v > best) {
                 best = v;
@@ -419,7 +454,7 @@ __global__ __launch_bounds__(256) void k_masked_max_fwd(const float* Z, int ldz,
     si[rl][fl] = bi;
     __syncthreads();
     if (rl == 0 && f < F) {
-        for (int k = 1; k < 4; ++k) {
+        for (int k = 1; k < 16; ++k) {
             const float v = sv[k][fl];
             const int i = si[k][fl];
             if (i >= 0 && (v > best || (v == best && i < bi))) {
@@ -440,7 +475,7 @@ __global__ __launch_bounds__(256) void k_masked_max_fwd(const float* Z, int ldz,
 void masked_max_fwd(Seq& q, const float* Z, int ldz, const int* num_nodes, float* out, int ldo, int* argmax,
                     int lda, int B, int n, int F) {
     if (!q.ok()) return;
-    hipLaunchKernelGGL(k_masked_max_fwd, dim3((F + 63) / 64, B), dim3(256), 0, q.stream, Z, ldz, num_nodes, out,
+    hipLaunchKernelGGL(k_masked_max_fwd, dim3((F + 63) / 64, B), dim3(1024), 0, q.stream, Z, ldz, num_nodes, out,
                        ldo, argmax, lda, n, F);
     q.check_launch("masked_max_fwd");
 }

@@ -58,6 +58,14 @@ int dp_bgemm_f32(const float* A, const float* B, float* C, const float* bias, in
                  int K, int lda, int ldb, int ldc, long strideA, long strideB, long strideC, int transA,
                  int transB, float alpha, float beta, int act, void* stream);
 
+/* ------------------------------------------------------------------ adjacency aggregation
+ * U[b] = op(adj[b]) · V[b] (+ beta U[b]):  adj [B,n,n], V [B,n,C] (ldv), U [B,n,C] (ldu); trans != 0 uses
+ * adj^T.  The HBM-bound pass over the padded dense adjacency — torch.matmul(adj, x), encoders.py:965,
+ * and its transpose in backward — as the LDS-panel kernel (any shape; shapes the panel kernel does not
+ * take run on dp_bgemm_f32's kernel). */
+int dp_adj_aggregate(const float* adj, const float* V, int ldv, float* U, int ldu, int B, int n, int C,
+                     int trans, float beta, void* stream);
+
 /* ------------------------------------------------------------------ A1  GraphConv
  * y = l2norm((adj @ x [+ x]) @ W + b)   — GraphConv.forward, encoders.py:962-974.
  * x [B,n,Fin] (ldx), adj [B,n,n], W [Fin,Fout], bias [Fout] or NULL, y [B,n,Fout] (ldy),

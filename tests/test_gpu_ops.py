@@ -73,6 +73,35 @@ def test_bgemm_asymmetric_identity_and_strides(lib):
     assert float(Cd[:, :, N:].abs().max()) == 0.0          # nothing written outside the N columns
 
 
+# ------------------------------------------------------------------ adjacency aggregation (panel kernel)
+@pytest.mark.parametrize("trans", [0, 1])
+@pytest.mark.parametrize("B,n,C", [(3, 16, 5), (2, 100, 40), (20, 500, 70), (2, 500, 128), (1, 1024, 33),
+                                   (2, 1100, 20), (2, 67, 9), (2, 260, 130)])
+def test_adj_aggregate(lib, trans, B, n, C):
+    g = torch.Generator().manual_seed(n + C)
+    adj = (torch.rand(B, n, n, generator=g) < 0.1).float() * torch.rand(B, n, n, generator=g)
+    V = torch.randn(B, n, C + 3, generator=g)            # ldv > C
+    U0 = torch.randn(B, n, C, generator=g)
+    ad, Vd, Ud = dev(adj), dev(V), dev(U0)
+    _lib.check(lib.dp_adj_aggregate(ad.data_ptr(), Vd.data_ptr(), C + 3, Ud.data_ptr(), C, B, n, C, trans, 0.5, S()))
+    opA = adj.transpose(1, 2) if trans else adj
+    ref = opA.double() @ V[:, :, :C].double() + 0.5 * U0.double()
+    close(Ud, ref.float(), 1e-4, 1e-4)
+
+
+def test_adj_aggregate_padding_is_inert(lib):
+    # graphs padded with zero rows/columns and NaN-free garbage beyond n must not leak into the result
+    B, n, C = 2, 36, 20
+    adj = torch.zeros(B, n, n)
+    adj[:, :30, :30] = (torch.rand(B, 30, 30) < 0.3).float()
+    V = torch.randn(B, n, C)
+    ad, Vd = dev(adj), dev(V)
+    U = torch.full((B, n, C), 7.0, device="cuda")
+    _lib.check(lib.dp_adj_aggregate(ad.data_ptr(), Vd.data_ptr(), C, U.data_ptr(), C, B, n, C, 0, 0.0, S()))
+    close(U, adj @ V, 1e-5, 1e-5)
+    assert float(U[:, 30:].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------ A1 GraphConv
 @pytest.mark.parametrize("add_self,bias,normalize", [(0, 1, 1), (1, 1, 1), (0, 0, 1), (1, 0, 0)])
 @pytest.mark.parametrize("B,n,fin,fout", [(3, 16, 5, 8), (2, 100, 89, 20), (2, 37, 20, 50)])
