@@ -402,8 +402,9 @@ int dp_set2set_fwd(const float* emb, int lde, const float* w_ih, const float* w_
                    const float* b_hh, const float* Wp, const float* bp, float* out, int B, int n, int d, void* save,
                    size_t save_bytes, void* stream) {
     NOTNULL(emb); NOTNULL(w_ih); NOTNULL(w_hh); NOTNULL(b_ih); NOTNULL(b_hh); NOTNULL(Wp); NOTNULL(bp); NOTNULL(out);
+    NOTNULL(save);
     NONNEG(B); NONNEG(n); NONNEG(d);
-    DP_CHECK_ARG(!save || save_bytes >= set2set_save_bytes(B, n, d), "set2set save buffer too small: %zu < %zu",
+    DP_CHECK_ARG(save_bytes >= set2set_save_bytes(B, n, d), "set2set save buffer too small: %zu < %zu",
                  save_bytes, set2set_save_bytes(B, n, d));
     Seq q(STREAM(stream), nullptr, 0);
     set2set_fwd(q, emb, lde, w_ih, w_hh, b_ih, b_hh, Wp, bp, out, B, n, d, save);

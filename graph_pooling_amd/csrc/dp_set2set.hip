@@ -1,22 +1,390 @@
-// Set2Set readout (set2set.py:32-57) — placeholder until the persistent kernel lands.
+// Set2Set readout (Set2Set.forward, set2set.py:32-57): n sequential steps of
+//     q, (h, c) = LSTM(q*, (h, c));  e = emb·q;  a = softmax over ALL n rows;  r = sum a·emb;  q* = [q, r]
+// then out = ReLU(Linear(q*)).  The reference runs 6 torch ops per step (n = N_pad steps: 305 ms per step of
+// pure launch latency at the ENZYMES shape).  Here the whole recurrence of a graph runs inside
+// ONE persistent workgroup: the LSTM weights sit in LDS for all n steps (transposed, W_ih[:, :d] + W_hh
+// pre-combined because q = h: gates = (W_ih[:, :d] + W_hh) h + W_ih[:, d:] r + b), the state never leaves
+// the CU, and the per-step state needed by backward streams to a save buffer.
+// Backward walks the steps in reverse inside one persistent workgroup per graph and only emits the per-step
+// vectors (d gates, d r, d e); every weight / embedding gradient is then a plain contraction over (graph, step)
+// done by the MFMA GEMM:  dW_ih = DG^T QP,  dW_hh = DG^T QP[:, :d],  demb = A^T DR + DE^T H.
 #include "dp_common.h"
 
 namespace dp {
 
-size_t set2set_save_bytes(int B, int n, int d) { return 256; }
+namespace {
 
-void set2set_fwd(Seq& q, const float*, int, const float*, const float*, const float*, const float*, const float*,
-                 const float*, float*, int, int, int, void*) {
-    if (q.err || q.dry) return;
-    set_error("Set2Set HIP kernel not built yet");
-    q.err = DP_ERR_UNSUPPORTED;
+struct S2SLayout {   // offsets in floats
+    size_t wt, qp, h, c, g, a, qn, total;
+    int GS;
+};
+S2SLayout s2s_layout(int B, int n, int d) {
+    S2SLayout L{};
+    L.GS = 4 * d + 1;
+    size_t off = 0;
+    auto take = [&](size_t cnt) {
+        size_t o = off;
+        off += (cnt + 63) & ~size_t(63);
+        return o;
+    };
+    L.wt = take((size_t)2 * d * L.GS);
+    L.qp = take((size_t)B * n * 2 * d);
+    L.h = take((size_t)B * n * d);
+    L.c = take((size_t)B * n * d);
+    L.g = take((size_t)B * n * 4 * d);
+    L.a = take((size_t)B * n * n);
+    L.qn = take((size_t)B * 2 * d);
+    L.total = off;
+    return L;
 }
-void set2set_bwd(Seq& q, const float*, int, const float*, const float*, const float*, const float*, const float*,
-                 const float*, const float*, const float*, float*, int, float*, float*, float*, float*, float*, float*,
-                 int, int, int, const void*) {
-    if (q.err || q.dry) return;
-    set_error("Set2Set HIP kernel not built yet");
-    q.err = DP_ERR_UNSUPPORTED;
+
+__device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ inline float team16_sum(float v) {
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    return v;
+}
+
+// block-wide reductions over 256 threads (red: 8 floats of LDS)
+__device__ inline float block_max(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ inline float block_sum(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// Wt[k][g] (row stride GS = 4d+1): k < d: W_ih[g][k] + W_hh[g][k];  d <= k < 2d: W_ih[g][k]
+__global__ void k_s2s_prep(const float* w_ih, const float* w_hh, float* wt, int d, int GS) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * d * 4 * d) return;
+    const int k = i / (4 * d), g = i % (4 * d);
+    float v = w_ih[(long)g * 2 * d + k];
+    if (k < d) v += w_hh[(long)g * d + k];
+    wt[(long)k * GS + g] = v;
+}
+
+struct S2SFwdArgs {
+    const float* emb;
+    int lde;
+    const float* wt;       // [2d][GS] global copy
+    const float* b_ih;
+    const float* b_hh;
+    const float* Wp;       // [d][2d]
+    const float* bp;
+    float* out;            // [B, d]
+    float *QP, *H, *Cs, *G, *Aw, *QN;   // save arrays (may be null: inference)
+    int n, d, GS;
+    int w_in_lds;
+};
+
+__global__ __launch_bounds__(256) void k_set2set_fwd(S2SFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.n, d = a.d, GS = a.GS;
+    float* lw = lds;                                   // [2d][GS] when w_in_lds
+    float* vec = lds + (a.w_in_lds ? 2 * d * GS : 0);
+    float* h = vec;                                    // [d]
+    float* c = h + d;                                  // [d]
+    float* r = c + d;                                  // [d]
+    float* gates = r + d;                              // [4d]
+    float* red = gates + 4 * d;                        // [8]
+    float* rpart = red + 8;                            // [4][64]
+    float* al = rpart + 256;                           // [n]
+    const float* W = a.w_in_lds ? lw : a.wt;
+    if (a.w_in_lds)
+        for (int i = tid; i < 2 * d * GS; i += 256) lw[i] = a.wt[i];
+    for (int i = tid; i < 3 * d; i += 256) vec[i] = 0.f;       // h, c, r = 0 (set2set.py:42-45)
+    __syncthreads();
+    const float* emb = a.emb + (long)b * n * a.lde;
+    const int tl = tid & 15, team = tid >> 4;
+
+    for (int t = 0; t < n; ++t) {
+        // ---- q*_{t-1} = [h, r] is the LSTM input of this step
+        if (a.QP)
+            for (int i = tid; i < 2 * d; i += 256) a.QP[((long)b * n + t) * 2 * d + i] = i < d ? h[i] : r[i - d];
+        // ---- gates = b + Wc h + Wr r
+        for (int g = tid; g < 4 * d; g += 256) {
+            float acc = a.b_ih[g] + a.b_hh[g];
+            for (int k = 0; k < d; ++k) acc += W[k * GS + g] * h[k];
+            for (int k = 0; k < d; ++k) acc += W[(d + k) * GS + g] * r[k];
+            gates[g] = acc;
+        }
+        __syncthreads();
+        // ---- LSTM cell (gate order i, f, g, o)
+        for (int j = tid; j < d; j += 256) {
+            const float ig = sigmoidf_(gates[j]), fg = sigmoidf_(gates[d + j]);
+            const float gg = tanhf(gates[2 * d + j]), og = sigmoidf_(gates[3 * d + j]);
+            const float cn = fg * c[j] + ig * gg;
+            const float hn = og * tanhf(cn);
+            c[j] = cn;
+            h[j] = hn;
+            if (a.G) {
+                float* gs = a.G + ((long)b * n + t) * 4 * d;
+                gs[j] = ig; gs[d + j] = fg; gs[2 * d + j] = gg; gs[3 * d + j] = og;
+                a.Cs[((long)b * n + t) * d + j] = cn;
+                a.H[((long)b * n + t) * d + j] = hn;
+            }
+        }
+        __syncthreads();
+        // ---- e = emb . h  (all n rows, padded rows included — set2set.py:50-51)
+        float lmax = -INFINITY;
+        for (int row = team; row < n; row += 16) {
+            const float* er = emb + (long)row * a.lde;
+            float s = 0.f;
+            for (int k = tl; k < d; k += 16) s += er[k] * h[k];
+            s = team16_sum(s);
+            if (tl == 0) al[row] = s;
+            lmax = fmaxf(lmax, s);
+        }
+        const float m = block_max(lmax, red);
+        float lsum = 0.f;
+        for (int row = tid; row < n; row += 256) {
+            const float p = expf(al[row] - m);
+            al[row] = p;
+            lsum += p;
+        }
+        const float inv = 1.f / block_sum(lsum, red);
+        for (int row = tid; row < n; row += 256) {
+            const float v = al[row] * inv;
+            al[row] = v;
+            if (a.Aw) a.Aw[((long)b * n + t) * n + row] = v;
+        }
+        __syncthreads();
+        // ---- r = sum_n a[n] emb[n]
+        for (int j0 = 0; j0 < d; j0 += 64) {
+            const int j = j0 + (tid & 63), part = tid >> 6;
+            float s = 0.f;
+            if (j < d)
+                for (int row = part; row < n; row += 4) s += al[row] * emb[(long)row * a.lde + j];
+            rpart[part * 64 + (tid & 63)] = s;
+            __syncthreads();
+            if (part == 0 && j < d) r[j] = rpart[tid] + rpart[64 + tid] + rpart[128 + tid] + rpart[192 + tid];
+            __syncthreads();
+        }
+    }
+    // ---- out = relu(Wp [h, r] + bp)
+    if (a.QN)
+        for (int i = tid; i < 2 * d; i += 256) a.QN[(long)b * 2 * d + i] = i < d ? h[i] : r[i - d];
+    for (int j = tid; j < d; j += 256) {
+        float acc = a.bp[j];
+        const float* wr = a.Wp + (long)j * 2 * d;
+        for (int k = 0; k < d; ++k) acc += wr[k] * h[k];
+        for (int k = 0; k < d; ++k) acc += wr[d + k] * r[k];
+        a.out[(long)b * d + j] = fmaxf(acc, 0.f);
+    }
+}
+
+struct S2SBwdArgs {
+    const float* emb;
+    int lde;
+    const float* wt;
+    const float* Wp;
+    const float* out;
+    const float* dout;
+    const float *H, *Cs, *G, *Aw;
+    float *DG, *DR, *DE, *DPRE;    // workspace outputs
+    int n, d, GS;
+    int w_in_lds;
+};
+
+__global__ __launch_bounds__(256) void k_set2set_bwd(S2SBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.n, d = a.d, GS = a.GS;
+    float* lw = lds;
+    float* vec = lds + (a.w_in_lds ? 2 * d * GS : 0);
+    float* dh = vec;                 // [d]
+    float* dc = dh + d;              // [d]
+    float* dr = dc + d;              // [d]
+    float* dg = dr + d;              // [4d]
+    float* red = dg + 4 * d;         // [8]
+    float* rpart = red + 8;          // [256]
+    float* de = rpart + 256;         // [n]
+    const float* W = a.w_in_lds ? lw : a.wt;
+    if (a.w_in_lds)
+        for (int i = tid; i < 2 * d * GS; i += 256) lw[i] = a.wt[i];
+    // ---- output layer: dpre = dout * (out > 0);  [dh, dr] = Wp^T dpre;  dc = 0
+    for (int j = tid; j < d; j += 256) {
+        const float o = a.out[(long)b * d + j];
+        const float v = o > 0.f ? a.dout[(long)b * d + j] : 0.f;
+        dg[j] = v;                                   // borrow dg[0:d] for dpre
+        a.DPRE[(long)b * d + j] = v;
+        dc[j] = 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < 2 * d; k += 256) {
+        float s = 0.f;
+        for (int j = 0; j < d; ++j) s += a.Wp[(long)j * 2 * d + k] * dg[j];
+        if (k < d) dh[k] = s; else dr[k - d] = s;
+    }
+    __syncthreads();
+    const float* emb = a.emb + (long)b * n * a.lde;
+    const int tl = tid & 15, team = tid >> 4;
+
+    for (int t = n - 1; t >= 0; --t) {
+        const float* at = a.Aw + ((long)b * n + t) * n;
+        // ---- r_t = sum a emb:  da = emb . dr ;  de = a * (da - sum a da)
+        for (int j = tid; j < d; j += 256) a.DR[((long)b * n + t) * d + j] = dr[j];
+        float lsum = 0.f;
+        for (int row = team; row < n; row += 16) {
+            const float* er = emb + (long)row * a.lde;
+            float s = 0.f;
+            for (int k = tl; k < d; k += 16) s += er[k] * dr[k];
+            s = team16_sum(s);
+            if (tl == 0) {
+                de[row] = s;
+                lsum += at[row] * s;
+            }
+        }
+        const float sdot = block_sum(lsum, red);
+        for (int row = tid; row < n; row += 256) {
+            const float v = at[row] * (de[row] - sdot);
+            de[row] = v;
+            a.DE[((long)b * n + t) * n + row] = v;
+        }
+        __syncthreads();
+        // ---- e = emb . h_t:  dh += sum_n de[n] emb[n]
+        for (int j0 = 0; j0 < d; j0 += 64) {
+            const int j = j0 + (tid & 63), part = tid >> 6;
+            float s = 0.f;
+            if (j < d)
+                for (int row = part; row < n; row += 4) s += de[row] * emb[(long)row * a.lde + j];
+            rpart[part * 64 + (tid & 63)] = s;
+            __syncthreads();
+            if (part == 0 && j < d) dh[j] += rpart[tid] + rpart[64 + tid] + rpart[128 + tid] + rpart[192 + tid];
+            __syncthreads();
+        }
+        // ---- LSTM cell backward
+        for (int j = tid; j < d; j += 256) {
+            const float* gs = a.G + ((long)b * n + t) * 4 * d;
+            const float ig = gs[j], fg = gs[d + j], gg = gs[2 * d + j], og = gs[3 * d + j];
+            const float ct = a.Cs[((long)b * n + t) * d + j];
+            const float cp = t > 0 ? a.Cs[((long)b * n + t - 1) * d + j] : 0.f;
+            const float tc = tanhf(ct);
+            const float dhj = dh[j];
+            const float dct = dc[j] + dhj * og * (1.f - tc * tc);
+            const float d_i = dct * gg * ig * (1.f - ig);
+            const float d_f = dct * cp * fg * (1.f - fg);
+            const float d_g = dct * ig * (1.f - gg * gg);
+            const float d_o = dhj * tc * og * (1.f - og);
+            dg[j] = d_i; dg[d + j] = d_f; dg[2 * d + j] = d_g; dg[3 * d + j] = d_o;
+            float* o = a.DG + ((long)b * n + t) * 4 * d;
+            o[j] = d_i; o[d + j] = d_f; o[2 * d + j] = d_g; o[3 * d + j] = d_o;
+            dc[j] = dct * fg;
+        }
+        __syncthreads();
+        // ---- [dh_{t-1}, dr_{t-1}] = Wt dg   (h_{t-1} and r_{t-1} feed only this step's LSTM)
+        for (int k = tid; k < 2 * d; k += 256) {
+            float s = 0.f;
+            const float* wr = W + (long)k * GS;
+            for (int g = 0; g < 4 * d; ++g) s += wr[g] * dg[g];
+            if (k < d) dh[k] = s; else dr[k - d] = s;
+        }
+        __syncthreads();
+    }
+}
+
+size_t s2s_dyn_lds(int n, int d, bool w_in_lds) {
+    const size_t GS = 4 * d + 1;
+    return ((w_in_lds ? (size_t)2 * d * GS : 0) + 7 * d + 8 + 256 + n + 16) * sizeof(float);
+}
+bool s2s_w_fits(int n, int d) { return s2s_dyn_lds(n, d, true) <= 158 * 1024; }
+
+}  // namespace
+
+size_t set2set_save_bytes(int B, int n, int d) { return s2s_layout(B, n, d).total * sizeof(float) + 256; }
+
+void set2set_fwd(Seq& q, const float* emb, int lde, const float* w_ih, const float* w_hh, const float* b_ih,
+                 const float* b_hh, const float* Wp, const float* bp, float* out, int B, int n, int d, void* save) {
+    if (q.err) return;
+    const S2SLayout L = s2s_layout(B, n, d);
+    if (!q.ok()) return;
+    if (s2s_dyn_lds(n, d, false) > 158 * 1024) {
+        set_error("Set2Set: n=%d does not fit the per-step LDS buffers", n);
+        q.err = DP_ERR_UNSUPPORTED;
+        return;
+    }
+    float* sv = (float*)save;
+    float* wt = sv + L.wt;
+    hipLaunchKernelGGL(k_s2s_prep, dim3((8 * d * d + 255) / 256), dim3(256), 0, q.stream, w_ih, w_hh, wt, d, L.GS);
+    q.check_launch("s2s_prep");
+    S2SFwdArgs a{};
+    a.emb = emb; a.lde = lde; a.wt = wt; a.b_ih = b_ih; a.b_hh = b_hh; a.Wp = Wp; a.bp = bp; a.out = out;
+    a.QP = sv + L.qp; a.H = sv + L.h; a.Cs = sv + L.c; a.G = sv + L.g; a.Aw = sv + L.a; a.QN = sv + L.qn;
+    a.n = n; a.d = d; a.GS = L.GS;
+    a.w_in_lds = s2s_w_fits(n, d) ? 1 : 0;
+    const size_t ldsb = s2s_dyn_lds(n, d, a.w_in_lds);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_set2set_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_set2set_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_set2set_fwd, dim3(B), dim3(256), ldsb, q.stream, a);
+    q.check_launch("set2set_fwd");
+}
+
+void set2set_bwd(Seq& q, const float* emb, int lde, const float* w_ih, const float* w_hh, const float* b_ih,
+                 const float* b_hh, const float* Wp, const float* bp, const float* out, const float* dout,
+                 float* demb, int ldde, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dWp,
+                 float* dbp, int B, int n, int d, const void* save) {
+    if (q.err) return;
+    const S2SLayout L = s2s_layout(B, n, d);
+    float* DG = q.alloc<float>((size_t)B * n * 4 * d);
+    float* DR = q.alloc<float>((size_t)B * n * d);
+    float* DE = q.alloc<float>((size_t)B * n * n);
+    float* DPRE = q.alloc<float>((size_t)B * d);
+    if (!q.ok()) return;
+    const float* sv = (const float*)save;
+    S2SBwdArgs a{};
+    a.emb = emb; a.lde = lde; a.wt = sv + L.wt; a.Wp = Wp; a.out = out; a.dout = dout;
+    a.H = sv + L.h; a.Cs = sv + L.c; a.G = sv + L.g; a.Aw = sv + L.a;
+    a.DG = DG; a.DR = DR; a.DE = DE; a.DPRE = DPRE;
+    a.n = n; a.d = d; a.GS = L.GS;
+    a.w_in_lds = s2s_w_fits(n, d) ? 1 : 0;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_set2set_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_set2set_bwd, dim3(B), dim3(256), s2s_dyn_lds(n, d, a.w_in_lds), q.stream, a);
+    q.check_launch("set2set_bwd");
+    const float* QP = sv + L.qp;
+    const float* QN = sv + L.qn;
+    const float* H = sv + L.h;
+    const float* Aw = sv + L.a;
+    const int T = n;
+    // output layer: dWp = dpre^T [h_n, r_n];  dbp = colsum(dpre)
+    bgemm(q, DPRE, QN, dWp, nullptr, 1, d, 2 * d, B, d, 2 * d, 2 * d, 0, 0, 0, true, false, 1.f, 0.f, 0);
+    colsum_batched(q, DPRE, d, 0, B, d, dbp, 0, 1);
+    // LSTM weights: contractions over all (graph, step) rows
+    {
+        GemmDesc g[2] = {
+            {DG, QP, dw_ih, nullptr, 4 * d, 2 * d, B * T, 4 * d, 2 * d, 2 * d, 0, 0, 0, true, false, 1.f, 0.f, 0},
+            {DG, QP, dw_hh, nullptr, 4 * d, d, B * T, 4 * d, 2 * d, d, 0, 0, 0, true, false, 1.f, 0.f, 0}};
+        bgemm_group(q, g, 2, 1);
+    }
+    colsum_batched(q, DG, 4 * d, 0, B * T, 4 * d, db_ih, 0, 1);
+    q.copy(db_hh, db_ih, (size_t)4 * d * sizeof(float));
+    // demb[b] = A_b^T DR_b + DE_b^T H_b
+    bgemm(q, Aw, DR, demb, nullptr, B, n, d, T, n, d, ldde, (long)T * n, (long)T * d, (long)n * ldde, true, false, 1.f,
+          0.f, 0);
+    bgemm(q, DE, H, demb, nullptr, B, n, d, T, n, d, ldde, (long)T * n, (long)T * d, (long)n * ldde, true, false, 1.f,
+          1.f, 0);
 }
 
 }  // namespace dp

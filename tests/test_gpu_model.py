@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 import torch
 
-from graph_pooling_amd.encoders import GcnEncoderGraph, SoftPoolingGcnEncoder
+from graph_pooling_amd.encoders import GcnEncoderGraph, GcnSet2SetEncoder, SoftPoolingGcnEncoder
+from graph_pooling_amd.set2set import Set2Set
 from oracle import diffpool_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -221,3 +222,65 @@ def test_linearity_of_pooling_at_full_size():
     close(P3, P1 + 2 * P2, 1e-4, 1e-4)
     # every row of S sums to 1  =>  sum(A') == sum(A)  (mass conservation of S^T A S)
     close(P1.sum(dim=(1, 2)), A1.sum(dim=(1, 2)), 1e-4, 1e-2)
+
+
+# ------------------------------------------------------------------ A10 Set2Set
+@pytest.mark.parametrize("n", [7, 100])
+def test_set2set_against_reference_golden(n, golden):
+    """Set2Set.forward / backward (set2set.py:32-57) through dp_set2set_fwd / dp_set2set_bwd.
+    The recurrence runs n steps, so reduction-order differences compound: rtol 2e-3 on gradients."""
+    a, params, grads = golden(f"g7_set2set_n{n}")
+    d = a["emb"].shape[2]
+    m = Set2Set(d, 2 * d)
+    m.load_state_dict(params)
+    m = m.cuda()
+    emb = T(a["emb"]).cuda().requires_grad_(True)
+    out = m(emb)
+    close(out, a["out"], 1e-4, 1e-5)
+    (out * T(a["gout"]).cuda()).sum().backward()
+    close(emb.grad, a["gemb"], 2e-3, 2e-5)
+    named = dict(m.named_parameters())
+    for k, g in grads.items():
+        close(named[k].grad, g, 2e-3, max(2e-5, 2e-4 * float(g.abs().max())))
+
+
+def test_set2set_encoder_against_reference_golden(golden):
+    a, params, grads = golden("g7_set2set_encoder")
+    x, adj = T(a["x"]), T(a["adj"])
+    B, N, F_ = x.shape
+    H = params["conv_first.weight"].shape[1]
+    E = params["conv_last.weight"].shape[1]
+    Cc = params["pred_model.weight"].shape[0]
+    model = GcnSet2SetEncoder(F_, H, E, Cc, 3)
+    model.load_state_dict(params)
+    model = model.cuda()
+    ypred = model(x.cuda(), adj.cuda(), a["num_nodes"])
+    close(ypred, a["ypred"])
+    loss = model.loss(ypred, T(a["label"]).cuda())
+    close(loss, a["loss"], 1e-5, 1e-6)
+    loss.backward()
+    grads_close(model, grads)
+
+
+def test_set2set_enzymes_shape_against_oracle():
+    # S-S2S (SURVEY §8(d)): B=20, N=100, D=60 -> LSTM(120 -> 60), 100 sequential steps
+    B, n, d = 20, 100, 60
+    g = torch.Generator().manual_seed(0)
+    emb = torch.randn(B, n, d, generator=g) * 0.3
+    emb[:, 70:] = 0.0
+    m = Set2Set(d, 2 * d)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda()
+    e_d = emb.cuda().requires_grad_(True)
+    out = m(e_d)
+    gout = torch.randn(B, d, generator=g)
+    (out * gout.cuda()).sum().backward()
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    e_o = emb.clone().requires_grad_(True)
+    oo = O.set2set_forward(e_o, P)
+    (oo * gout).sum().backward()
+    close(out, oo, 1e-4, 1e-5)
+    close(e_d.grad, e_o.grad, 2e-3, 2e-5)
+    named = dict(m.named_parameters())
+    for k, v in P.items():
+        close(named[k].grad, v.grad, 2e-3, max(2e-5, 2e-4 * float(v.grad.abs().max())))
