@@ -113,6 +113,9 @@ def load():
                 f"{LIB_PATH} not found: the DiffPool HIP extension is not built. Run "
                 "graph_pooling_amd/csrc/build.sh (or `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "There is no PyTorch fallback for this path.")
+        # torch must load ITS libamdhip64 first: the .so then binds to that already-loaded runtime. Loading
+        # ours first puts two HIP runtimes in one process and the second one finds no device.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(lib, name)      # AttributeError if the .so does not export what the header declares

@@ -18,6 +18,8 @@
 //                 (each lane reads 4 consecutive k; the V fragment loads use the same k order)
 // TN panel image: [n][32] (8 rows per 1-KiB DMA piece) -> ds_read_b32, 2-way conflicts (minor next to
 //                 the 32-cycle MFMA)
+#include <cstdlib>
+
 #include "dp_common.h"
 
 namespace dp {
@@ -31,6 +33,8 @@ struct AggArgs {
     const float* V;      // [B, n, C] (ldv)
     int ldv;
     int n, C;
+    int tiles;           // row tiles per graph
+    int dbg;             // ablation switches (DP_AGG_DEBUG): 1 no multiply loop, 2 no panel DMA, 4 no V loads
     // plain epilogue
     float* U;            // [B, n, C] (ldu) or null
     int ldu;
@@ -45,7 +49,6 @@ struct AggArgs {
     int normalize, stats_mode;
 };
 
-constexpr int AGG_RT = 32;         // output rows per workgroup
 constexpr int AGG_KP = 1024;       // K columns per LDS panel (NN); 128-KiB panels at most
 
 __device__ inline void dma16(const float* src, float* lds_dst) {
@@ -61,11 +64,23 @@ __device__ inline float agg_team_sum(float v) {
     return v;
 }
 
-template <bool TRANS, int CT>
+template <bool TRANS, int CT, int AGG_RT>
 __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
+    constexpr int MI = AGG_RT / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.y;
-    const int r0 = blockIdx.x * AGG_RT;
+    // XCD-aware work mapping: consecutive block ids are dealt round-robin over the 8 XCDs (each with its own
+    // L2), so block id -> work id is remapped (bijectively) to give every XCD one CONTIGUOUS run of
+    // (graph, row tile) items: the 16 row tiles of a graph then share one L2 for their V operand instead of
+    // fetching it into all eight (measured: 32 MB -> ~22 MB of fabric reads per DD launch).
+    const int nwg = gridDim.x, tiles = a.tiles;
+    int wid;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qd = nwg >> 3, rm = nwg & 7;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int b = wid / tiles;
+    const int r0 = (wid % tiles) * AGG_RT;
     const int n = a.n;
     const float* A = a.A + (long)b * n * n;
     const float* V = a.V + (long)b * n * a.ldv;
@@ -73,40 +88,64 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
 
-    f32x4 acc[2][CT];
+    f32x4 acc[MI][CT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int kpanel = TRANS ? n : min(n, AGG_KP);
     const int segs = (kpanel + 255) / 256;
-    const int ldp = TRANS ? 32 : segs * 256 + 4;      // NN: = 4 (mod 64)
+    const int ldp = TRANS ? AGG_RT : segs * 256 + 4;  // NN: = 4 (mod 64)
 
     for (int kbase = 0; kbase < n; kbase += kpanel) {
         const int kw = min(kpanel, n - kbase);        // valid K columns in this panel
-        // ---------------- V fragments for this wave's first TWO steps go out ahead of the panel burst, so
-        // they are not queued behind 64 KB of adjacency in this CU's memory pipeline
+        // ---------------- V fragments: three statically named register buffers rotate through the k-steps
+        // (the loop is unrolled x3, so no register copies and the compiler can wait with a COUNTED vmcnt: the
+        // fragments multiplied in a step were requested two steps earlier).  Loads are unconditional on
+        // clamped addresses (no exec-mask branches); out-of-range elements are zeroed by a select.  The first
+        // two steps' fragments go out ahead of the panel burst so they do not queue behind 32-64 KB of adjacency.
         const int steps = (kw + 15) / 16;
-        float bv[4][CT], bn[4][CT], bn2[4][CT];
+        float b0[4][CT], b1[4][CT], b2[4][CT];
         auto load_b = [&](int step, float (&dst)[4][CT]) {
+            // no predicate and no select on the loaded values: rows are clamped to n-1 (the padded K tail of the
+            // LDS panel is zeroed below, so those products vanish), columns >= C are clamped duplicates that
+            // land in output columns nobody stores
             const int k0 = kbase + step * 16 + kq * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = k0 + j;
-                const bool kok = (step < steps) && (k < kbase + kw);
+                const float* vrow = V + (long)min(k0 + j, n - 1) * a.ldv;
 #pragma unroll
-                for (int cb = 0; cb < CT; ++cb) {
-                    const int c = cb * 16 + l15;
-                    dst[j][cb] = (kok && c < a.C) ? V[(long)k * a.ldv + c] : 0.f;
-                }
+                for (int cb = 0; cb < CT; ++cb) dst[j][cb] = vrow[min(cb * 16 + l15, a.C - 1)];
             }
         };
-        load_b(wave, bv);
-        load_b(wave + 4, bn);
+        auto mma = [&](int step, const float (&bf)[4][CT]) {
+            const int kl = step * 16 + kq * 4;         // panel-local k of this lane's 4 values
+            float av[MI][4];
+#pragma unroll
+            for (int rb = 0; rb < MI; ++rb) {
+                if (!TRANS) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(lds + (rb * 16 + l15) * ldp + kl);
+                    av[rb][0] = t[0]; av[rb][1] = t[1]; av[rb][2] = t[2]; av[rb][3] = t[3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) av[rb][j] = lds[(kl + j) * AGG_RT + rb * 16 + l15];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < MI; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < CT; ++cb)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][j], bf[j][cb], acc[rb][cb], 0, 0, 0);
+        };
+        load_b(wave, b0);
+        load_b(wave + 4, b1);
         // ---------------- panel -> LDS (everything in flight at once)
-        if (!TRANS) {
-            // rows r0..r0+31, columns kbase..kbase+kw: pieces (row i, segment s) of 256 floats
+        if (a.dbg & 2) {
+        } else if (!TRANS) {
+            // rows r0..r0+RT-1, columns kbase..kbase+kw: pieces (row i, segment s) of 256 floats
             const int pieces = AGG_RT * segs;
             for (int pc = wave; pc < pieces; pc += 4) {
                 const int i = pc / segs, s = pc % segs;
@@ -116,44 +155,39 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
                 dma16(A + (long)row * n + col, lds + i * ldp + s * 256);
             }
         } else {
-            // columns r0..r0+31 of rows k: pieces of 8 rows x 128 B; every row a k-step can touch is
-            // written (rows >= n are finite duplicates of row n-1 and meet zero V rows)
-            const int pieces = ((kw + 15) / 16) * 2;
+            // columns r0..r0+RT-1 of rows k: 1-KiB pieces of (256/RT) rows x RT floats; every row a k-step can
+            // touch is written (rows >= n are finite duplicates of row n-1 and meet zero V rows)
+            constexpr int RPP = 256 / AGG_RT;            // panel rows per piece
+            constexpr int LPR = AGG_RT / 4;              // lanes per row
+            const int pieces = (((kw + 15) / 16) * 16) / RPP;
             for (int pc = wave; pc < pieces; pc += 4) {
-                const int k = min(kbase + pc * 8 + (lane >> 3), n - 1);
-                const int col = min(r0 + (lane & 7) * 4, n - 4);
+                const int k = min(kbase + pc * RPP + lane / LPR, n - 1);
+                const int col = min(r0 + (lane % LPR) * 4, n - 4);
                 dma16(A + (long)k * n + col, lds + pc * 256);
             }
         }
         __syncthreads();                               // drains the DMA (vmcnt(0)) and publishes the panel
-        for (int step = wave; step < steps; step += 4) {
-            load_b(step + 8, bn2);
-            const int kl = step * 16 + kq * 4;         // panel-local k of this lane's 4 values
-            float av[2][4];
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                if (!TRANS) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(lds + (rb * 16 + l15) * ldp + kl);
-                    av[rb][0] = t[0]; av[rb][1] = t[1]; av[rb][2] = t[2]; av[rb][3] = t[3];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) av[rb][j] = lds[(kl + j) * 32 + rb * 16 + l15];
-                }
+        if (kw & 15) {
+            // zero the padded K tail [kw, ceil16(kw)) of the panel (it holds finite duplicates)
+            const int k1 = steps * 16, tail = k1 - kw;
+            for (int e = threadIdx.x; e < tail * AGG_RT; e += 256) {
+                if (!TRANS) lds[(e / tail) * ldp + kw + e % tail] = 0.f;
+                else lds[(kw + e / AGG_RT) * AGG_RT + e % AGG_RT] = 0.f;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int cb = 0; cb < CT; ++cb)
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][j], bv[j][cb], acc[rb][cb], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int cb = 0; cb < CT; ++cb) {
-                    bv[j][cb] = bn[j][cb];
-                    bn[j][cb] = bn2[j][cb];
-                }
+            __syncthreads();
+        }
+        const int send = (a.dbg & 1) ? 0 : steps;
+        for (int step = wave; step < send; step += 12) {
+            load_b(step + 8, b2);
+            mma(step, b0);
+            if (step + 4 < send) {
+                load_b(step + 12, b0);
+                mma(step + 4, b1);
+            }
+            if (step + 8 < send) {
+                load_b(step + 16, b1);
+                mma(step + 8, b2);
+            }
         }
         __syncthreads();                               // panel may be overwritten (next K panel / reduction)
     }
@@ -162,7 +196,7 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     constexpr int CTP = CT * 16 + 1;
     float* red = lds;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < MI; ++rb)
 #pragma unroll
         for (int cb = 0; cb < CT; ++cb)
 #pragma unroll
@@ -240,30 +274,42 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     }
 }
 
-static size_t agg_lds_bytes(bool trans, int n, int CT) {
+static size_t agg_lds_bytes(bool trans, int n, int CT, int RT) {
     const int kpanel = trans ? n : (n < AGG_KP ? n : AGG_KP);
     const int segs = (kpanel + 255) / 256;
-    const size_t panel = trans ? (size_t)((n + 15) / 16) * 512 : (size_t)AGG_RT * (segs * 256 + 4);
-    const size_t red = (size_t)5 * AGG_RT * (CT * 16 + 1);
+    const size_t panel = trans ? (size_t)((n + 15) / 16) * 16 * RT : (size_t)RT * (segs * 256 + 4);
+    const size_t red = (size_t)5 * RT * (CT * 16 + 1);
     return (panel > red ? panel : red) * sizeof(float);
 }
+// 16-row tiles when 32-row tiles would leave the chip with < 2 workgroups per CU (small batches): twice the
+// workgroups, four co-resident per CU, so one workgroup's panel burst overlaps its neighbours' multiplies.
+static int agg_row_tile(int B, int n) { return ((long)((n + 31) / 32) * B >= 512) ? 32 : 16; }
 
 bool aggregate_supported(const float* A, int n, int C, bool trans) {
     if (n < 4 || n % 4 != 0 || C < 1 || C > 128) return false;
     if ((reinterpret_cast<uintptr_t>(A) & 15) != 0) return false;
-    return agg_lds_bytes(trans, n, (C + 15) / 16) <= 160 * 1024;
+    return agg_lds_bytes(trans, n, (C + 15) / 16, 32) <= 160 * 1024;
 }
 
-template <bool TRANS, int CT>
-static void launch_agg(Seq& q, const AggArgs& a, int B) {
-    const size_t lds = agg_lds_bytes(TRANS, a.n, CT);
+template <bool TRANS, int CT, int RT>
+static void launch_agg_rt(Seq& q, const AggArgs& a, int B) {
+    const size_t lds = agg_lds_bytes(TRANS, a.n, CT, RT);
     static bool attr_done = false;   // per instantiation: allow > 64 KiB of dynamic LDS
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate<TRANS, CT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate<TRANS, CT, RT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_aggregate<TRANS, CT>), dim3((a.n + AGG_RT - 1) / AGG_RT, B), dim3(256), lds, q.stream, a);
+    AggArgs aa = a;
+    aa.tiles = (a.n + RT - 1) / RT;
+    static const int dbg = getenv("DP_AGG_DEBUG") ? atoi(getenv("DP_AGG_DEBUG")) : 0;
+    aa.dbg = dbg;
+    hipLaunchKernelGGL((k_aggregate<TRANS, CT, RT>), dim3(aa.tiles * B), dim3(256), lds, q.stream, aa);
+}
+template <bool TRANS, int CT>
+static void launch_agg(Seq& q, const AggArgs& a, int B) {
+    if (agg_row_tile(B, a.n) == 32) launch_agg_rt<TRANS, CT, 32>(q, a, B);
+    else launch_agg_rt<TRANS, CT, 16>(q, a, B);
 }
 
 template <bool TRANS>
