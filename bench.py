@@ -145,14 +145,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the DiffPool HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DP_BENCH_REHEARSE=1: all ranks share GPU 0 and talk over gloo — lets the N > 1 code path be exercised
+    # on a one-GPU box (RCCL refuses two ranks on one device). Never used for reported numbers.
+    rehearse = os.environ.get("DP_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} rank(s)", file=sys.stderr)
 
@@ -232,7 +239,8 @@ def main():
             "value": round(value, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": w["name"], "graphs_per_gpu": w["B"], "global_batch": w["B"] * world,
+            "config": {"workload": w["name"] + (" [REHEARSAL: ranks share one GPU over gloo]" if rehearse else ""),
+                       "graphs_per_gpu": w["B"], "global_batch": w["B"] * world,
                        "linkpred": bool(args.linkpred), "hip_graph": graph is not None,
                        "parallelism": f"dp{world}"},
         }

@@ -101,8 +101,12 @@ struct GemmDesc {
     bool tA, tB;
     float alpha, beta;
     int act;
+    long sK;       // split-K: partial of K range ks goes to C + ks*sK (0: all ranges share C)
+    int atomic;    // split-K ranges add into C with float atomics
 };
-void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch);
+// ksplit > 1 cuts K into ranges run by different workgroups (contractions over the node index have K = n
+// = 500 but outputs of a few KB: without it they are 40-80 workgroups walking 16 dependent k-steps).
+void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit = 1);
 
 // Column groups of a row: the level-j embed and assign GCN stacks share one pass over the
 // adjacency, so row-wise kernels work on up to two column groups of a joint buffer.
@@ -147,7 +151,7 @@ void reduce_bias(Seq& q, const BiasReduceTable& t, float* grads);
 void colsum_batched(Seq& q, const float* X, int ldx, long strideX, int rows, int cols, float* out,
                     long strideOut, int batch);
 void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, const int* num_nodes, int B,
-                      int n, int K);
+                      int n, int K, float* S2 = nullptr);
 void softmax_mask_bwd(Seq& q, const float* S, int lds, const float* dS, int ldds, const int* num_nodes,
                       float* dlogits, int ldl, int B, int n, int K);
 void masked_max_fwd(Seq& q, const float* Z, int ldz, const int* num_nodes, float* out, int ldo, int* argmax,
@@ -167,6 +171,18 @@ void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ld
 bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, const float* P, GroupCPtrs bias,
                            RowGroups g, GroupPtrs yout, float* invn, float* part, int B, int n, int normalize,
                            int stats_mode);
+
+// (dp_small.hip) one-workgroup-per-graph GCN layers of a pooled level (n <= 64)
+bool small_level_supported(int B, int n, int din, int dout);
+void small_gcn_fwd(Seq& q, const float* adj, const float* x0, int ldx0, const float* yprev, int ldyp,
+                   const float* part_prev, float* stats_prev, float* xout, int ldxo, const float* W, const float* bias,
+                   float* y, int ldy, float* invn, float* part, int B, int n, int din, int dout, int add_self,
+                   int stats);
+void small_gcn_bwd(Seq& q, const float* adj, const float* xin, int ldxin, const float* W, const float* y, int ldy,
+                   const float* xhat, int ldxh, const float* invn, const float* stats, const float* part2,
+                   const float* dx, int lddx, float* dxin, int lddxin, float* part2_prev, float* dadj, float* dW,
+                   float* db, long slab_stride, int B, int n, int din, int dout, int add_self, int has_bn,
+                   int has_relu);
 
 // (dp_linkpred.hip)
 void linkpred_fwd(Seq& q, const float* S, int lds, const float* adj, const int* num_nodes, float* loss_out,

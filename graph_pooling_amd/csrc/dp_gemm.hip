@@ -39,6 +39,9 @@ struct GemmArgs {
     int tilesN;
     int vecA, vecB;   // operand may be read with 16-byte loads
     int tA, tB;
+    int ksplit;       // K is cut into `ksplit` ranges handled by different workgroups (blockIdx.y = b*ksplit + ks)
+    long sK;          // != 0: range ks stores its partial at C + ks*sK (slab rows, summed by the caller's reduce)
+    int atomic;       // 1: ranges add into C with float atomics (C pre-zeroed / accumulated into; no bias/act)
 };
 
 constexpr int KT = 32;
@@ -140,11 +143,16 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
     float* Bs = lds + ((LA::SIZE + 3) & ~3);
 
     const int tm = tile / a.tilesN, tn = tile % a.tilesN;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y / a.ksplit, ks = blockIdx.y % a.ksplit;
     const float* A = a.A + (long)b * a.sA;
     const float* B = a.B + (long)b * a.sB;
-    float* C = a.C + (long)b * a.sC;
+    float* C = a.C + (long)b * a.sC + (long)ks * a.sK;
     const int m0 = tm * BM, n0 = tn * BN;
+    // this workgroup's K range (whole slabs of KT)
+    const int kchunk = ((a.K + a.ksplit * KT - 1) / (a.ksplit * KT)) * KT;
+    const int kbeg = ks * kchunk;
+    const int kend = min(a.K, kbeg + kchunk);
+    if (kbeg >= kend && ks > 0 && a.sK == 0) return;   // nothing to add to a shared C
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -157,16 +165,16 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (a.K + KT - 1) / KT;
+    const int nk = kend > kbeg ? (kend - kbeg + KT - 1) / KT : 0;
     Slab<BM> ra0, ra1;
     Slab<BN> rb0, rb1;
     if (nk > 0) {
-        slab_load<BM, !TA>(A, a.lda, m0, 0, a.M, a.K, a.vecA, ra0);
-        slab_load<BN, TB>(B, a.ldb, n0, 0, a.N, a.K, a.vecB, rb0);
+        slab_load<BM, !TA>(A, a.lda, m0, kbeg, a.M, kend, a.vecA, ra0);
+        slab_load<BN, TB>(B, a.ldb, n0, kbeg, a.N, kend, a.vecB, rb0);
     }
     if (nk > 1) {
-        slab_load<BM, !TA>(A, a.lda, m0, KT, a.M, a.K, a.vecA, ra1);
-        slab_load<BN, TB>(B, a.ldb, n0, KT, a.N, a.K, a.vecB, rb1);
+        slab_load<BM, !TA>(A, a.lda, m0, kbeg + KT, a.M, kend, a.vecA, ra1);
+        slab_load<BN, TB>(B, a.ldb, n0, kbeg + KT, a.N, kend, a.vecB, rb1);
     }
 
     auto compute = [&]() {
@@ -190,8 +198,8 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
         slab_store<BN, TB>(Bs, rb0);
         __syncthreads();
         if (kt + 2 < nk) {
-            slab_load<BM, !TA>(A, a.lda, m0, (kt + 2) * KT, a.M, a.K, a.vecA, ra0);
-            slab_load<BN, TB>(B, a.ldb, n0, (kt + 2) * KT, a.N, a.K, a.vecB, rb0);
+            slab_load<BM, !TA>(A, a.lda, m0, kbeg + (kt + 2) * KT, a.M, kend, a.vecA, ra0);
+            slab_load<BN, TB>(B, a.ldb, n0, kbeg + (kt + 2) * KT, a.N, kend, a.vecB, rb0);
         }
         compute();
         __syncthreads();
@@ -200,8 +208,8 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
             slab_store<BN, TB>(Bs, rb1);
             __syncthreads();
             if (kt + 3 < nk) {
-                slab_load<BM, !TA>(A, a.lda, m0, (kt + 3) * KT, a.M, a.K, a.vecA, ra1);
-                slab_load<BN, TB>(B, a.ldb, n0, (kt + 3) * KT, a.N, a.K, a.vecB, rb1);
+                slab_load<BM, !TA>(A, a.lda, m0, kbeg + (kt + 3) * KT, a.M, kend, a.vecA, ra1);
+                slab_load<BN, TB>(B, a.ldb, n0, kbeg + (kt + 3) * KT, a.N, kend, a.vecB, rb1);
             }
             compute();
             __syncthreads();
@@ -221,8 +229,12 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
                 const int row = m0 + wr * WM + i * 16 + l4 * 4 + r;
                 if (row >= a.M) continue;
                 float* cp = C + (long)row * a.ldc + col;
+                if (a.atomic) {
+                    atomicAdd(cp, a.alpha * acc[i][j][r]);
+                    continue;
+                }
                 float v = a.alpha * acc[i][j][r] + bv;
-                if (a.beta != 0.f) v += a.beta * (*cp);
+                if (a.beta != 0.f && (ks == 0 || a.sK != 0)) v += a.beta * (*cp);
                 if (a.act == 1) v = fmaxf(v, 0.f);
                 *cp = v;
             }
@@ -270,14 +282,16 @@ static void launch_tile(Seq& q, GemmGroupArgs& g, int batch) {
         total += ((a.M + BM - 1) / BM) * a.tilesN;
     }
     g.tile0[g.count] = total;
-    hipLaunchKernelGGL((bgemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(total, batch), dim3(256), 0, q.stream, g);
+    hipLaunchKernelGGL((bgemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(total, batch * g.p[0].ksplit), dim3(256), 0,
+                       q.stream, g);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch) {
+void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
     if (!q.ok() || batch <= 0 || count <= 0) return;
-    if (batch > 65535 || count > GEMM_GROUP_MAX) {
+    if (ksplit < 1) ksplit = 1;
+    if ((long)batch * ksplit > 65535 || count > GEMM_GROUP_MAX) {
         set_error("bgemm_group: batch %d / count %d out of range", batch, count);
         q.err = DP_ERR_INVALID_ARG;
         return;
@@ -289,7 +303,7 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch) {
         if (s.M <= 0 || s.N <= 0) continue;
         GemmArgs& a = g.p[g.count++];
         a = GemmArgs{s.A, s.B, s.C, s.bias, s.M, s.N, s.K, s.lda, s.ldb, s.ldc, s.sA, s.sB, s.sC, s.alpha, s.beta,
-                     s.act, 0, 0, 0, s.tA ? 1 : 0, s.tB ? 1 : 0};
+                     s.act, 0, 0, 0, s.tA ? 1 : 0, s.tB ? 1 : 0, ksplit, s.sK, s.atomic};
         a.vecA = aligned16(s.A) && (s.lda % 4 == 0) && (s.sA % 4 == 0);
         a.vecB = aligned16(s.B) && (s.ldb % 4 == 0) && (s.sB % 4 == 0);
         if (s.N > maxN) maxN = s.N;
@@ -303,7 +317,7 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch) {
     auto wgs = [&](int bm, int bn) {
         long t = 0;
         for (int i = 0; i < g.count; ++i)
-            t += (long)((g.p[i].M + bm - 1) / bm) * ((g.p[i].N + bn - 1) / bn) * batch;
+            t += (long)((g.p[i].M + bm - 1) / bm) * ((g.p[i].N + bn - 1) / bn) * batch * ksplit;
         return t;
     };
     if (maxN <= 16) {
@@ -323,8 +337,8 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch) {
 void bgemm(Seq& q, const float* A, const float* B, float* C, const float* bias, int batch, int M, int N,
            int K, int lda, int ldb, int ldc, long sA, long sB, long sC, bool tA, bool tB, float alpha,
            float beta, int act) {
-    GemmDesc d{A, B, C, bias, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, alpha, beta, act};
-    bgemm_group(q, &d, 1, batch);
+    GemmDesc d{A, B, C, bias, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, alpha, beta, act, 0, 0};
+    bgemm_group(q, &d, 1, batch, 1);
 }
 
 }  // namespace dp

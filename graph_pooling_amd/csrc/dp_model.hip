@@ -192,6 +192,21 @@ RowGroups groups_of(const LevelInfo& li, int l) {
     return g;
 }
 
+// Split-K factor of the contractions over the node index (and the slab-row multiplier): small batches of
+// big graphs need it to fill the chip, large batches do not.
+int node_ksplit(const dp_encoder_cfg& c) {
+    if (c.B >= 64) return 1;
+    int ks = (c.N + 127) / 128;
+    return ks < 1 ? 1 : (ks > 8 ? 8 : ks);
+}
+
+bool level_is_small(int B, const LevelInfo& li) {
+    if (li.G != 1) return false;
+    for (int l = 0; l < li.L; ++l)
+        if (!small_level_supported(B, li.n, li.e->dims[l], li.e->dims[l + 1])) return false;
+    return true;
+}
+
 struct LevelIO {
     const float* x0e;  // embed stack input [B, n, dims_e[0]]
     const float* x0a;  // assign stack input [B, n, dims_a[0]]
@@ -224,10 +239,26 @@ void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const Level
 }
 
 void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
-                   const float* params, float* Pj, float* Uj, float* part) {
+                   const float* params, float* Pj, float* Uj, float* part, float* part_b) {
     const int B = c.B, n = li.n;
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
+    if (level_is_small(B, li)) {
+        // pooled level (or tiny graphs): one launch per layer, one workgroup per graph (dp_small.hip)
+        float* pbuf[2] = {part, part_b};
+        for (int l = 0; l < li.L; ++l) {
+            const bool last = l == li.L - 1;
+            const int din = li.e->dims[l], dout = li.e->dims[l + 1];
+            small_gcn_fwd(q, io.adj, l == 0 ? io.x0e : nullptr, din, l > 0 ? lv.layer[l - 1].Y : nullptr,
+                          l > 0 ? li.ctot[l - 1] : 0, (l > 0 && bn) ? pbuf[(l - 1) & 1] : nullptr,
+                          l > 0 ? lv.layer[l - 1].stats : nullptr, l > 0 ? lv.Ze + li.coff_e[l - 1] : nullptr, li.D,
+                          PW(params, li.e->w_off[l]), PW(params, li.e->b_off[l]),
+                          last ? lv.Ze + li.coff_e[l] : lv.layer[l].Y, last ? li.D : li.ctot[l], lv.layer[l].invn,
+                          (!last && bn) ? pbuf[l & 1] : nullptr, B, n, din, dout, add_self ? 1 : 0,
+                          (!last && bn) ? 1 : 0);
+        }
+        return;
+    }
     for (int l = 0; l < li.L; ++l) {
         const int ct = li.ctot[l];
         const bool last = l == li.L - 1;
@@ -276,11 +307,33 @@ struct LevelGrad {
 };
 
 void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
-                    const float* params, const LevelGrad& gr, float* slabs, long slab_stride, float* Pj, float* dUj,
-                    float* Gj, float* part, float* const* bpart, BiasReduceTable& btab) {
+                    const float* params, const LevelGrad& gr, float* slabs, long slab_stride, int KS, float* Pj,
+                    float* dUj, float* Gj, float* part, float* part_b, float* const* bpart, BiasReduceTable& btab) {
     const int B = c.B, n = li.n;
+    const long gstride = slab_stride * KS;     // slab rows of one graph: KS split-K partials
+    const int ks_level = n >= 256 ? KS : 1;
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
+    if (level_is_small(B, li)) {
+        float* pbuf[2] = {part, part_b};
+        for (int l = li.L - 1; l >= 0; --l) {
+            const bool last = l == li.L - 1;
+            const bool has_bn = !last && bn;
+            const int din = li.e->dims[l], dout = li.e->dims[l + 1];
+            const float* xin = l == 0 ? io.x0e : lv.Ze + li.coff_e[l - 1];
+            const int ldxin = l == 0 ? din : li.D;
+            float* dxin = l > 0 ? gr.dZe + li.coff_e[l - 1] : gr.dX0;
+            const int lddxin = l > 0 ? li.D : din;
+            small_gcn_bwd(q, io.adj, xin, ldxin, PW(params, li.e->w_off[l]),
+                          last ? lv.Ze + li.coff_e[l] : lv.layer[l].Y, last ? li.D : li.ctot[l],
+                          has_bn ? lv.Ze + li.coff_e[l] : nullptr, li.D, lv.layer[l].invn, lv.layer[l].stats,
+                          has_bn ? pbuf[l & 1] : nullptr, gr.dZe + li.coff_e[l], li.D, dxin, lddxin,
+                          (l > 0 && bn && dxin) ? pbuf[(l - 1) & 1] : nullptr, gr.dAdj, slabs + li.e->w_off[l],
+                          li.e->b_off[l] >= 0 ? slabs + li.e->b_off[l] : nullptr, gstride, B, n, din, dout,
+                          add_self ? 1 : 0, has_bn ? 1 : 0, last ? 0 : 1);
+        }
+        return;
+    }
     for (int l = li.L - 1; l >= 0; --l) {
         const int ct = li.ctot[l];
         const bool last = l == li.L - 1;
@@ -335,7 +388,7 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
                 }
                 // dW slab[b] = x_in[b]^T G[b]
                 d[nd++] = GemmDesc{xin, Gj + g.c0[gi], slabs + st->w_off[l], nullptr, din, dout, n, ldin, ct, dout,
-                                   (long)n * ldin, (long)n * ct, slab_stride, true, false, 1.f, 0.f, 0};
+                                   (long)n * ldin, (long)n * ct, gstride, true, false, 1.f, 0.f, 0, slab_stride, 0};
                 // gradient w.r.t. the layer input: G W^T (accumulated into the concat-gradient slice)
                 float* dxin = nullptr;
                 int lddx = 0;
@@ -346,11 +399,12 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
                     dxin = gr.dX0;
                     lddx = din;
                 }
-                if (dxin)
+                if (dxin)   // accumulates into dZ: atomic so split-K ranges (only > 1 for wide layers) cannot race
                     d[nd++] = GemmDesc{Gj + g.c0[gi], PW(params, st->w_off[l]), dxin, nullptr, n, din, dout, ct, dout,
-                                       lddx, (long)n * ct, 0, (long)n * lddx, false, true, 1.f, 1.f, 0};
+                                       lddx, (long)n * ct, 0, (long)n * lddx, false, true, 1.f, 1.f, 0, 0,
+                                       ks_level > 1 ? 1 : 0};
             }
-            bgemm_group(q, d, nd, B);
+            bgemm_group(q, d, nd, B, ks_level);
             // both stacks of a pooled level read the same input X_j: the assign stack's share is added after
             if (l == 0 && gr.dX0 && li.G == 2) {
                 const dp_stack_cfg* st = li.a;
@@ -368,7 +422,7 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
 }
 
 struct Scratch {
-    float *Pj, *Uj, *part, *logits;
+    float *Pj, *Uj, *part, *part_b, *logits;
 };
 
 // shared allocation walk for the forward (also used for sizing)
@@ -385,6 +439,7 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
     s.Pj = q.alloc<float>(maxPU);
     s.Uj = q.alloc<float>(maxPU);
     s.part = q.alloc<float>(maxPart);
+    s.part_b = q.alloc<float>(maxPart);
     s.logits = q.alloc<float>(maxLog > 0 ? maxLog : 1);
     return s;
 }
@@ -406,7 +461,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
         io.x0e = j == 0 ? x : sv.lv[j - 1].Xn;
         io.x0a = j == 0 ? assign_x : sv.lv[j - 1].Xn;
         io.adj = j == 0 ? adj : sv.lv[j - 1].An;
-        level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part);
+        level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part, sc.part_b);
         const int* nn_j = (j == 0) ? num_nodes : nullptr;
         if (c.readout == 0) {
             const int rw = readout_width(c, li);
@@ -425,15 +480,23 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
             // S = softmax(Za Wp^T + bp) * mask
             bgemm(q, lv.Za, PW(params, c.assign_pred_w_off[j]), sc.logits, PW(params, c.assign_pred_b_off[j]), B, n, K,
                   li.Da, li.Da, li.Da, K, (long)n * li.Da, 0, (long)n * K, false, true, 1.f, 0.f, 0);
-            softmax_mask_fwd(q, sc.logits, K, lv.S, K, nn_j, B, n, K);
-            if (j == 0 && assign_out) q.copy(assign_out, lv.S, (size_t)B * n * K * sizeof(float));
+            softmax_mask_fwd(q, sc.logits, K, lv.S, K, nn_j, B, n, K, j == 0 ? assign_out : nullptr);
             // X' = S^T Z ; T = S^T A ; A' = T S
-            // X' = S^T Z ;  Tt = A^T S  (= (S^T A)^T, [n x K]) ;  A' = Tt^T S
-            bgemm(q, lv.S, lv.Ze, lv.Xn, nullptr, B, K, li.D, n, K, li.D, li.D, (long)n * K, (long)n * li.D,
-                  (long)K * li.D, true, false, 1.f, 0.f, 0);
+            // X' = S^T Z ;  Tt = A^T S  (= (S^T A)^T, [n x K]) ;  A' = Tt^T S.   X' and A' contract over the node
+            // index (K = n): split-K with float atomics into the zeroed outputs when the level is large
+            const int ksn = n >= 256 ? node_ksplit(c) : 1;
+            if (ksn > 1) q.zero(lv.Xn, (size_t)((char*)(lv.An + (size_t)B * K * K) - (char*)lv.Xn));
+            {
+                GemmDesc d{lv.S, lv.Ze, lv.Xn, nullptr, K, li.D, n, K, li.D, li.D, (long)n * K, (long)n * li.D,
+                           (long)K * li.D, true, false, 1.f, 0.f, 0, 0, ksn > 1 ? 1 : 0};
+                bgemm_group(q, &d, 1, B, ksn);
+            }
             aggregate(q, io.adj, lv.S, K, lv.T, K, B, n, K, true, 0.f);
-            bgemm(q, lv.T, lv.S, lv.An, nullptr, B, K, K, n, K, K, K, (long)n * K, (long)n * K, (long)K * K, true, false,
-                  1.f, 0.f, 0);
+            {
+                GemmDesc d{lv.T, lv.S, lv.An, nullptr, K, K, n, K, K, K, (long)n * K, (long)n * K, (long)K * K, true,
+                           false, 1.f, 0.f, 0, 0, ksn > 1 ? 1 : 0};
+                bgemm_group(q, &d, 1, B, ksn);
+            }
         }
     }
     // pred_model
@@ -482,11 +545,13 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     float* dUj = q.alloc<float>(maxPU);
     float* Gj = q.alloc<float>(maxPU);
     float* part = q.alloc<float>(maxPart);
+    float* part_b = q.alloc<float>(maxPart);
     float* dS = q.alloc<float>(maxSK ? maxSK : 1);
     float* dlog = q.alloc<float>(maxSK ? maxSK : 1);
     float* V = q.alloc<float>(maxSK ? maxSK : 1);
     float* V2 = q.alloc<float>(maxSK ? maxSK : 1);
-    float* slabs = q.alloc<float>((size_t)B * (c.n_graph_params > 0 ? c.n_graph_params : 1));
+    const int KS = node_ksplit(c);
+    float* slabs = q.alloc<float>((size_t)B * KS * (c.n_graph_params > 0 ? c.n_graph_params : 1));
     float* dh[DP_MAX_PRED + 2];
     for (int i = 0; i < c.n_pred; ++i) dh[i] = q.alloc<float>((size_t)B * c.pred_dims[i]);
     dh[c.n_pred] = const_cast<float*>(d_ypred);   // read only
@@ -501,6 +566,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     // every entry of `grads` is written below (weights: slab reduce / direct GEMM; biases: reduce_bias /
     // column sums), so no memset of it is needed
     q.zero(q.ws + zero_begin, zero_end - zero_begin);
+    if (KS > 1) q.zero(slabs, (size_t)B * KS * c.n_graph_params * sizeof(float));   // unused split-K rows must be 0
     // ---- pred_model backward
     for (int i = c.n_pred - 1; i >= 0; --i) {
         const int din = c.pred_dims[i], dout = c.pred_dims[i + 1];
@@ -571,19 +637,20 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
             softmax_mask_bwd(q, lv.S, K, dS, K, j == 0 ? num_nodes : nullptr, dlog, K, B, n, K);
             // assign_pred: logits = Za Wp^T + bp
             {
-                GemmDesc d[2] = {
-                    {dlog, lv.Za, slabs + c.assign_pred_w_off[j], nullptr, K, li.Da, n, K, li.Da, li.Da, (long)n * K,
-                     (long)n * li.Da, slab_stride, true, false, 1.f, 0.f, 0},
-                    {dlog, PW(params, c.assign_pred_w_off[j]), gr[j].dZa, nullptr, n, li.Da, K, K, li.Da, li.Da,
-                     (long)n * K, 0, (long)n * li.Da, false, false, 1.f, 0.f, 0}};
-                bgemm_group(q, d, 2, B);
+                const int ksn = n >= 256 ? KS : 1;
+                GemmDesc dw{dlog, lv.Za, slabs + c.assign_pred_w_off[j], nullptr, K, li.Da, n, K, li.Da, li.Da,
+                            (long)n * K, (long)n * li.Da, slab_stride * KS, true, false, 1.f, 0.f, 0, slab_stride, 0};
+                bgemm_group(q, &dw, 1, B, ksn);
+                bgemm(q, dlog, PW(params, c.assign_pred_w_off[j]), gr[j].dZa, nullptr, B, n, li.Da, K, K, li.Da, li.Da,
+                      (long)n * K, 0, (long)n * li.Da, false, false, 1.f, 0.f, 0);
             }
             if (c.assign_pred_b_off[j] >= 0)
-                colsum_batched(q, dlog, K, (long)n * K, n, K, slabs + c.assign_pred_b_off[j], slab_stride, B);
+                colsum_batched(q, dlog, K, (long)n * K, n, K, slabs + c.assign_pred_b_off[j], slab_stride * KS, B);
         }
-        level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, Pj, dUj, Gj, part, bpart[j], btab);
+        level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, KS, Pj, dUj, Gj, part, part_b, bpart[j],
+                       btab);
     }
-    reduce_slabs(q, slabs, slab_stride, B, grads, c.n_graph_params, 0);
+    reduce_slabs(q, slabs, slab_stride, B * KS, grads, c.n_graph_params, 0);
     reduce_bias(q, btab, grads);
     return q.err;
 }

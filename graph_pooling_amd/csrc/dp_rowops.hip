@@ -297,12 +297,12 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
         }
     }
 }
-int rownorm_bwd_chunks(int n) { return (n + 31) / 32; }
+int rownorm_bwd_chunks(int n) { return (n + 7) / 8; }
 void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const float* invn, const float* stats,
                  const float* part2, RowGroups g, float* dU, int ldu, float* bpart, int B, int n, int has_relu,
                  int has_bn, int normalize) {
     if (!q.ok()) return;
-    RownormBwdArgs a{dx, xhat, y, invn, stats, part2, g, dU, ldu, bpart, B, n, 32, has_relu, has_bn, normalize};
+    RownormBwdArgs a{dx, xhat, y, invn, stats, part2, g, dU, ldu, bpart, B, n, 8, has_relu, has_bn, normalize};
     const int ct = g.c0[g.G - 1] + g.w[g.G - 1];
     hipLaunchKernelGGL(k_rownorm_bwd, dim3(rownorm_bwd_chunks(n), B), dim3(256),
                        bpart ? 16 * ct * sizeof(float) : 0, q.stream, a);
@@ -369,7 +369,7 @@ void colsum_batched(Seq& q, const float* X, int ldx, long strideX, int rows, int
 // ------------------------------------------------------------------ softmax * mask
 // S = softmax_K(logits) for n < num_nodes[b], 0 otherwise  (encoders.py:1273-1275)
 __global__ __launch_bounds__(256) void k_softmax_mask_fwd(const float* logits, int ldl, float* S, int lds,
-                                                          const int* num_nodes, long rows, int n, int K) {
+                                                          float* S2, const int* num_nodes, long rows, int n, int K) {
     const int tl = threadIdx.x & 15;
     const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const long nteams = (long)gridDim.x * 16;
@@ -378,8 +378,12 @@ __global__ __launch_bounds__(256) void k_softmax_mask_fwd(const float* logits, i
         const bool valid = num_nodes ? node < num_nodes[b] : true;
         const float* l = logits + row * ldl;
         float* s = S + row * lds;
+        float* s2 = S2 ? S2 + row * lds : nullptr;   // second copy (the caller-visible assign_tensor)
         if (!valid) {
-            for (int c = tl; c < K; c += 16) s[c] = 0.f;
+            for (int c = tl; c < K; c += 16) {
+                s[c] = 0.f;
+                if (s2) s2[c] = 0.f;
+            }
             continue;
         }
         float m = -INFINITY;
@@ -389,14 +393,18 @@ __global__ __launch_bounds__(256) void k_softmax_mask_fwd(const float* logits, i
         for (int c = tl; c < K; c += 16) sum += expf(l[c] - m);
         sum = team_sum(sum);
         const float r = 1.f / sum;
-        for (int c = tl; c < K; c += 16) s[c] = expf(l[c] - m) * r;
+        for (int c = tl; c < K; c += 16) {
+            const float v = expf(l[c] - m) * r;
+            s[c] = v;
+            if (s2) s2[c] = v;
+        }
     }
 }
 void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, const int* num_nodes, int B, int n,
-                      int K) {
+                      int K, float* S2) {
     if (!q.ok()) return;
     const long rows = (long)B * n;
-    hipLaunchKernelGGL(k_softmax_mask_fwd, dim3(team_grid(rows)), dim3(256), 0, q.stream, logits, ldl, S, lds,
+    hipLaunchKernelGGL(k_softmax_mask_fwd, dim3(team_grid(rows)), dim3(256), 0, q.stream, logits, ldl, S, lds, S2,
                        num_nodes, rows, n, K);
     q.check_launch("softmax_mask_fwd");
 }
@@ -442,6 +450,7 @@ __global__ __launch_bounds__(1024) void k_masked_max_fwd(const float* Z, int ldz
     int bi = -1;
     if (f < F) {
         const float* z = Z + (long)b * n * ldz + f;
+#pragma unroll 4
         for (int r = rl; r < nb; r += 16) {
             const float v = z[(long)r * ldz];
             if (v > best) {

@@ -1,0 +1,379 @@
+// GCN layers of a POOLED level (n = K_j <= 64 nodes per graph, e.g. 50 at the DD shape, 10 at ENZYMES):
+// gcn_forward over (X', A') after the pooling step (encoders.py:1282-1284, 1054-1081) and its backward.
+// The generic path spends ~13 forward + ~25 backward launches of 4-8 us on a level whose whole per-graph
+// state (A' 50x50, X' 50x60, W 60x20) is a few tens of KB.  Here ONE workgroup per graph runs a complete
+// layer out of LDS — transform, aggregation, bias, l2-normalise, BN statistics forward;  BN/ReLU/normalise
+// backward, bias sums, A'^T dU, dW, dX, dA' backward — so a layer is one launch each way (the cross-graph
+// BatchNorm statistics still force one grid-wide boundary per layer; they travel as per-row partials and each
+// workgroup combines the B partials of its node indices itself).
+// Plain fp32 FMA loops: ~0.1 MFLOP per graph per layer, latency-bound whatever the ALU.
+#include "dp_common.h"
+
+namespace dp {
+
+#define SM_L2_EPS 1e-12f
+#define SM_BN_EPS 1e-5f
+
+namespace {
+
+__device__ inline float sm_team_sum(float v) {
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    return v;
+}
+
+typedef float sm_f32x4 __attribute__((ext_vector_type(4)));
+
+// C[M x N] = op(A)[M x K] · op(B)[K x N] with both operands in LDS, on the fp32 MFMA (16x16x4), tiles dealt
+// round-robin to the workgroup's waves.  Reads outside the logical matrices return 0, so nothing needs
+// padding.  `store(i, j, v)` receives every in-range result element.
+template <bool TA, bool TB, typename Store>
+__device__ inline void lds_mma(const float* A, int lda, const float* B, int ldb, int M, int N, int K, Store store) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int tm = (M + 15) / 16, tn = (N + 15) / 16;
+    for (int t = wave; t < tm * tn; t += nwaves) {
+        const int i = (t / tn) * 16 + l15, j = (t % tn) * 16 + l15;
+        sm_f32x4 acc = (sm_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + kq;
+            const bool kok = k < K;
+            const float av = (kok && i < M) ? (TA ? A[k * lda + i] : A[i * lda + k]) : 0.f;
+            const float bv = (kok && j < N) ? (TB ? B[j * ldb + k] : B[k * ldb + j]) : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (t / tn) * 16 + kq * 4 + r;
+            if (row < M && j < N) store(row, j, acc[r]);
+        }
+    }
+}
+
+struct SmallFwdArgs {
+    const float* adj;      // [B, n, n]
+    const float* x0;       // layer 0: raw input [B, n, din] (ld = ldx0); else null
+    int ldx0;
+    const float* yprev;    // layer > 0: previous layer's normalised pre-ReLU output [B, n, din] (ld = ldyp)
+    int ldyp;
+    const float* part_prev;  // [B, n, 2] (row mean, row M2) of relu(yprev), or null (no BN)
+    float* stats_prev;       // [n, 2] out (mu, rstd) of the previous layer
+    float* xout;           // layer > 0: BN output of the previous layer -> concat buffer slice (ld = ldxo)
+    int ldxo;
+    const float* W;        // [din, dout]
+    const float* bias;     // [dout] or null
+    float* y;              // [B, n, dout] out (ld = ldy)
+    int ldy;
+    float* invn;           // [B, n]
+    float* part;           // [B, n, 2] out or null
+    int B, n, din, dout;
+    int add_self, stats;
+};
+
+// Every global input is staged into LDS in ONE burst (one round of global latency); all phases after the
+// first barrier read LDS only.
+__global__ __launch_bounds__(1024) void k_small_gcn_fwd(SmallFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.n, din = a.din, dout = a.dout;
+    float* A = lds;                    // [n][n]
+    float* X = A + n * n;              // [n][din]
+    float* W = X + n * din;            // [din][dout]
+    float* P = W + din * dout;         // [n][dout]
+    float* U = P + n * dout;           // [n][dout]
+    float* mu = U + n * dout;          // [n]
+    float* rs = mu + n;                // [n]
+    float* PP = rs + n;                // [B][n][2] staged BN partials of the previous layer
+    const int tl = tid & 15, team = tid >> 4;
+    const int NT = blockDim.x, NTEAMS = blockDim.x >> 4;
+    const bool bnprev = !a.x0 && a.part_prev;
+
+    for (int i = tid; i < n * n; i += NT) A[i] = a.adj[(long)b * n * n + i];
+    for (int i = tid; i < din * dout; i += NT) W[i] = a.W[i];
+    if (a.x0) {
+        for (int r = team; r < n; r += NTEAMS)
+            for (int k = tl; k < din; k += 16) X[r * din + k] = a.x0[((long)b * n + r) * a.ldx0 + k];
+    } else {
+        for (int r = team; r < n; r += NTEAMS)
+            for (int k = tl; k < din; k += 16) X[r * din + k] = a.yprev[((long)b * n + r) * a.ldyp + k];
+        if (bnprev)
+            for (int i = tid; i < a.B * n * 2; i += NT) PP[i] = a.part_prev[i];
+    }
+    __syncthreads();
+    if (!a.x0) {
+        // BN statistics of the previous layer per node index (Chan-combine of the B row partials)
+        for (int r = tid; r < n; r += NT) {
+            float m = 0.f, rstd = 1.f;
+            if (bnprev) {
+                float sm = 0.f;
+                for (int bb = 0; bb < a.B; ++bb) sm += PP[(bb * n + r) * 2];
+                m = sm / (float)a.B;
+                float s2 = 0.f;
+                for (int bb = 0; bb < a.B; ++bb) {
+                    const float d = PP[(bb * n + r) * 2] - m;
+                    s2 += PP[(bb * n + r) * 2 + 1] + (float)din * d * d;
+                }
+                rstd = 1.0f / sqrtf(s2 / ((float)a.B * (float)din) + SM_BN_EPS);
+                if (b == 0) {
+                    a.stats_prev[r * 2] = m;
+                    a.stats_prev[r * 2 + 1] = rstd;
+                }
+            }
+            mu[r] = m;
+            rs[r] = rstd;
+        }
+        __syncthreads();
+        for (int r = team; r < n; r += NTEAMS)
+            for (int k = tl; k < din; k += 16) {
+                const float v = (fmaxf(X[r * din + k], 0.f) - mu[r]) * rs[r];
+                X[r * din + k] = v;
+                a.xout[((long)b * n + r) * a.ldxo + k] = v;
+            }
+        __syncthreads();
+    }
+    // P = X W
+    lds_mma<false, false>(X, din, W, dout, n, dout, din, [&](int r, int c, float v) { P[r * dout + c] = v; });
+    __syncthreads();
+    // U = A P (+ P) + bias
+    lds_mma<false, false>(A, n, P, dout, n, dout, n, [&](int r, int c, float v) {
+        if (a.add_self) v += P[r * dout + c];
+        if (a.bias) v += a.bias[c];
+        U[r * dout + c] = v;
+    });
+    __syncthreads();
+    // l2-normalise rows, BN partials of relu(y)
+    for (int r = team; r < n; r += NTEAMS) {
+        const long row = (long)b * n + r;
+        float ss = 0.f;
+        for (int c = tl; c < dout; c += 16) ss += U[r * dout + c] * U[r * dout + c];
+        ss = sm_team_sum(ss);
+        const float inv = 1.f / fmaxf(sqrtf(ss), SM_L2_EPS);
+        float s1 = 0.f;
+        for (int c = tl; c < dout; c += 16) {
+            const float v = U[r * dout + c] * inv;
+            a.y[row * a.ldy + c] = v;
+            s1 += fmaxf(v, 0.f);
+        }
+        if (tl == 0) a.invn[row] = inv;
+        if (a.stats) {
+            s1 = sm_team_sum(s1);
+            const float mean = s1 / (float)dout;
+            float m2 = 0.f;
+            for (int c = tl; c < dout; c += 16) {
+                const float v = fmaxf(U[r * dout + c] * inv, 0.f) - mean;
+                m2 += v * v;
+            }
+            m2 = sm_team_sum(m2);
+            if (tl == 0) {
+                a.part[row * 2] = mean;
+                a.part[row * 2 + 1] = m2;
+            }
+        }
+    }
+}
+
+struct SmallBwdArgs {
+    const float* adj;      // [B, n, n]
+    const float* xin;      // layer input [B, n, din] (ld = ldxin): raw x0 or the BN output slice of layer l-1
+    int ldxin;
+    const float* W;        // [din, dout]
+    const float* y;        // this layer's normalised output [B, n, dout] (ld = ldy)
+    int ldy;
+    const float* xhat;     // BN output of this layer (ld = ldxh) — null for the last layer
+    int ldxh;
+    const float* invn;     // [B, n]
+    const float* stats;    // [n, 2] of this layer
+    const float* part2;    // [B, n, 2] (sum dx, sum dx*xhat) of this layer — null for the last layer
+    const float* dx;       // gradient w.r.t. this layer's output [B, n, dout] (ld = lddx)
+    int lddx;
+    float* dxin;           // gradient w.r.t. the layer input, ACCUMULATED [B, n, din] (ld = lddxin), or null
+    int lddxin;
+    float* part2_prev;     // [B, n, 2] out: BN-backward partials of layer l-1 (needs dxin), or null
+    float* dadj;           // [B, n, n] accumulated, or null
+    float* dW;             // slab of this graph: [din, dout]   (slab_stride between graphs)
+    float* db;             // slab of this graph: [dout] or null
+    long slab_stride;
+    int B, n, din, dout;
+    int add_self, has_bn, has_relu;
+};
+
+__global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.n, din = a.din, dout = a.dout;
+    float* A = lds;                    // [n][n]
+    float* X = A + n * n;              // [n][din]   layer input
+    float* W = X + n * din;            // [din][dout]
+    float* dU = W + din * dout;        // [n][dout]  staged dx, then dU in place
+    float* G = dU + n * dout;          // [n][dout]
+    float* P = G + n * dout;           // [n][dout]  staged y, then P = X W
+    float* XH = P + n * dout;          // [n][dout]  staged xhat (BN layers)
+    float* DX = XH + n * dout;         // [n][din]   gradient w.r.t. the layer input (running total)
+    float* IV = DX + n * din;          // [n] 1/||u||
+    float* M0 = IV + n;                // [n]
+    float* M1 = M0 + n;                // [n]
+    float* PP = M1 + n;                // [B][n][2] staged BN-backward partials
+    const int tl = tid & 15, team = tid >> 4;
+    const int NT = blockDim.x, NTEAMS = blockDim.x >> 4;
+    float* dWb = a.dW + (long)b * a.slab_stride;
+    float* dbb = a.db ? a.db + (long)b * a.slab_stride : nullptr;
+
+    // ---- one burst: everything this layer reads from global
+    for (int i = tid; i < n * n; i += NT) A[i] = a.adj[(long)b * n * n + i];
+    for (int i = tid; i < din * dout; i += NT) W[i] = a.W[i];
+    for (int r = team; r < n; r += NTEAMS) {
+        const long row = (long)b * n + r;
+        for (int k = tl; k < din; k += 16) {
+            X[r * din + k] = a.xin[row * a.ldxin + k];
+            if (a.dxin) DX[r * din + k] = a.dxin[row * a.lddxin + k];
+        }
+        for (int c = tl; c < dout; c += 16) {
+            dU[r * dout + c] = a.dx[row * a.lddx + c];
+            P[r * dout + c] = a.y[row * a.ldy + c];
+            if (a.has_bn) XH[r * dout + c] = a.xhat[row * a.ldxh + c];
+        }
+        if (tl == 0) IV[r] = a.invn[row];
+    }
+    if (a.has_bn)
+        for (int i = tid; i < a.B * n * 2; i += NT) PP[i] = a.part2[i];
+    __syncthreads();
+    if (a.has_bn) {
+        for (int r = tid; r < n; r += NT) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int bb = 0; bb < a.B; ++bb) {
+                s0 += PP[(bb * n + r) * 2];
+                s1 += PP[(bb * n + r) * 2 + 1];
+            }
+            const float cnt = (float)a.B * (float)dout;
+            M0[r] = s0 / cnt;
+            M1[r] = s1 / cnt;
+        }
+        __syncthreads();
+    }
+    // ---- dU = normalise^T relu^T bn^T dx (in place over the staged dx), one team per row
+    for (int r = team; r < n; r += NTEAMS) {
+        const float rstd = a.has_bn ? a.stats[r * 2 + 1] : 1.f;
+        const float m0 = a.has_bn ? M0[r] : 0.f, m1 = a.has_bn ? M1[r] : 0.f;
+        const float inv = IV[r];
+        const bool project = inv < 1.0f / SM_L2_EPS;
+        float dot = 0.f;
+        for (int c = tl; c < dout; c += 16) {
+            float d = dU[r * dout + c];
+            const float yy = P[r * dout + c];
+            if (a.has_bn) d = rstd * (d - m0 - XH[r * dout + c] * m1);
+            if (a.has_relu) d = yy > 0.f ? d : 0.f;
+            dU[r * dout + c] = d;
+            dot += d * yy;
+        }
+        dot = sm_team_sum(dot);
+        for (int c = tl; c < dout; c += 16) {
+            const float d = dU[r * dout + c];
+            dU[r * dout + c] = project ? inv * (d - P[r * dout + c] * dot) : inv * d;
+        }
+    }
+    __syncthreads();
+    // ---- db = column sums of dU ;  G = A^T dU (+ dU) ;  P = X W
+    if (dbb)
+        for (int c = tid; c < dout; c += NT) {
+            float s = 0.f;
+            for (int r = 0; r < n; ++r) s += dU[r * dout + c];
+            dbb[c] = s;
+        }
+    lds_mma<true, false>(A, n, dU, dout, n, dout, n, [&](int m, int c, float v) {
+        G[m * dout + c] = a.add_self ? v + dU[m * dout + c] : v;
+    });
+    if (a.dadj)
+        lds_mma<false, false>(X, din, W, dout, n, dout, din, [&](int m, int c, float v) { P[m * dout + c] = v; });
+    __syncthreads();
+    // ---- dW = X^T G  -> this graph's slab
+    lds_mma<true, false>(X, din, G, dout, din, dout, n, [&](int k, int c, float v) { dWb[k * dout + c] = v; });
+    // ---- dXin = G W^T, accumulated into the gradient of the layer input
+    if (a.dxin)
+        lds_mma<false, true>(G, dout, W, dout, n, din, dout, [&](int r, int k, float v) {
+            const float tot = DX[r * din + k] + v;
+            DX[r * din + k] = tot;
+            a.dxin[((long)b * n + r) * a.lddxin + k] = tot;
+        });
+    // ---- dA += dU P^T
+    if (a.dadj)
+        lds_mma<false, true>(dU, dout, P, dout, n, n, dout, [&](int r, int m, float v) {
+            a.dadj[(long)b * n * n + r * n + m] += v;
+        });
+    // ---- BN-backward partials of layer l-1: (sum_k dX[r][k], sum_k dX[r][k] xhat[r][k]); xhat_{l-1} = X
+    if (a.part2_prev) {
+        __syncthreads();
+        for (int r = team; r < n; r += NTEAMS) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int k = tl; k < din; k += 16) {
+                const float d = DX[r * din + k];
+                s0 += d;
+                s1 += d * X[r * din + k];
+            }
+            s0 = sm_team_sum(s0);
+            s1 = sm_team_sum(s1);
+            if (tl == 0) {
+                a.part2_prev[((long)b * n + r) * 2] = s0;
+                a.part2_prev[((long)b * n + r) * 2 + 1] = s1;
+            }
+        }
+    }
+}
+
+size_t small_lds_floats_fwd(int B, int n, int din, int dout) {
+    return (size_t)n * n + (size_t)n * din + (size_t)din * dout + 2 * (size_t)n * dout + 2 * n + (size_t)B * n * 2 + 16;
+}
+size_t small_lds_floats_bwd(int B, int n, int din, int dout) {
+    return (size_t)n * n + 2 * (size_t)n * din + (size_t)din * dout + 4 * (size_t)n * dout + 3 * n +
+           (size_t)B * n * 2 + 16;
+}
+
+}  // namespace
+
+bool small_level_supported(int B, int n, int din, int dout) {
+    if (n > 64 || din > 256 || dout > 256) return false;
+    const size_t f = small_lds_floats_fwd(B, n, din, dout), bw = small_lds_floats_bwd(B, n, din, dout);
+    return (f > bw ? f : bw) * sizeof(float) <= 150 * 1024;
+}
+
+static void small_attr() {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_gcn_fwd),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_gcn_bwd),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done = true;
+    }
+}
+
+void small_gcn_fwd(Seq& q, const float* adj, const float* x0, int ldx0, const float* yprev, int ldyp,
+                   const float* part_prev, float* stats_prev, float* xout, int ldxo, const float* W, const float* bias,
+                   float* y, int ldy, float* invn, float* part, int B, int n, int din, int dout, int add_self,
+                   int stats) {
+    if (!q.ok()) return;
+    small_attr();
+    SmallFwdArgs a{adj, x0, ldx0, yprev, ldyp, part_prev, stats_prev, xout, ldxo, W, bias, y, ldy, invn, part,
+                   B, n, din, dout, add_self, stats};
+    hipLaunchKernelGGL(k_small_gcn_fwd, dim3(B), dim3(1024), small_lds_floats_fwd(B, n, din, dout) * sizeof(float),
+                       q.stream, a);
+    q.check_launch("small_gcn_fwd");
+}
+
+void small_gcn_bwd(Seq& q, const float* adj, const float* xin, int ldxin, const float* W, const float* y, int ldy,
+                   const float* xhat, int ldxh, const float* invn, const float* stats, const float* part2,
+                   const float* dx, int lddx, float* dxin, int lddxin, float* part2_prev, float* dadj, float* dW,
+                   float* db, long slab_stride, int B, int n, int din, int dout, int add_self, int has_bn,
+                   int has_relu) {
+    if (!q.ok()) return;
+    small_attr();
+    SmallBwdArgs a{adj, xin, ldxin, W, y, ldy, xhat, ldxh, invn, stats, part2, dx, lddx, dxin, lddxin, part2_prev,
+                   dadj, dW, db, slab_stride, B, n, din, dout, add_self, has_bn, has_relu};
+    hipLaunchKernelGGL(k_small_gcn_bwd, dim3(B), dim3(1024), small_lds_floats_bwd(B, n, din, dout) * sizeof(float),
+                       q.stream, a);
+    q.check_launch("small_gcn_bwd");
+}
+
+}  // namespace dp
