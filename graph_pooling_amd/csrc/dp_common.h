@@ -134,22 +134,12 @@ void mask_rows(Seq& q, const float* src, int lds, float* dst, int ldd, const int
 void bn_bwd_partials(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, RowGroups g, float* part, long rows);
 void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat /*BN output, null when no BN*/, GroupCPtrs y,
                  const float* invn, const float* stats, const float* part2, RowGroups g, float* dU, int ldu,
-                 float* bpart /*[B, rownorm_bwd_chunks(n), ldu] column sums of dU, or null*/, int B, int n,
-                 int has_relu, int has_bn, int normalize);
+                 const GroupPtrs* dbias /*per group: bias-gradient slab of graph 0 (ld = distance between graphs);
+                 column sums of dU are atomically added; null: none*/, int B, int n, int has_relu, int has_bn,
+                 int normalize);
 int rownorm_bwd_chunks(int n);
-struct BiasReduceEntry {
-    const float* src;   // [rows, ld]
-    int rows, ld, c0, w;
-    long dst;           // offset in the flat gradient buffer
-};
-#define BIAS_TABLE_MAX ((DP_MAX_LEVELS + 1) * DP_MAX_LAYERS * 2)
-struct BiasReduceTable {
-    int count;
-    BiasReduceEntry e[BIAS_TABLE_MAX];
-};
-void reduce_bias(Seq& q, const BiasReduceTable& t, float* grads);
 void colsum_batched(Seq& q, const float* X, int ldx, long strideX, int rows, int cols, float* out,
-                    long strideOut, int batch);
+                    long strideOut, int batch, int rowsplit = 1);
 void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, const int* num_nodes, int B,
                       int n, int K, float* S2 = nullptr);
 void softmax_mask_bwd(Seq& q, const float* S, int lds, const float* dS, int ldds, const int* num_nodes,

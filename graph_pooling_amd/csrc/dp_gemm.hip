@@ -317,7 +317,8 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
     auto wgs = [&](int bm, int bn) {
         long t = 0;
         for (int i = 0; i < g.count; ++i)
-            t += (long)((g.p[i].M + bm - 1) / bm) * ((g.p[i].N + bn - 1) / bn) * batch * ksplit;
+            t += (long)((g.p[i].M + bm - 1) / bm) * ((g.p[i].N + bn - 1) / bn) * batch;   // split-K not counted:
+        // it exists to add parallelism to small-output problems, not to license bigger tiles
         return t;
     };
     if (maxN <= 16) {

@@ -308,7 +308,7 @@ struct LevelGrad {
 
 void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
                     const float* params, const LevelGrad& gr, float* slabs, long slab_stride, int KS, float* Pj,
-                    float* dUj, float* Gj, float* part, float* part_b, float* const* bpart, BiasReduceTable& btab) {
+                    float* dUj, float* Gj, float* part, float* part_b) {
     const int B = c.B, n = li.n;
     const long gstride = slab_stride * KS;     // slab rows of one graph: KS split-K partials
     const int ks_level = n >= 256 ? KS : 1;
@@ -359,15 +359,13 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
         }
         const bool has_bn = !last && bn;
         if (has_bn) bn_bwd_partials(q, dx, xhat, g, part, (long)B * n);
-        rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, part, g, dUj, ct, bpart[l], B, n, !last,
-                    has_bn, 1);
-        // bias gradients: per-(graph, chunk) column sums of dU, reduced once at the end of the backward
-        for (int gi = 0; gi < li.G; ++gi) {
-            const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
-            if (st->b_off[l] >= 0 && btab.count < BIAS_TABLE_MAX)
-                btab.e[btab.count++] = BiasReduceEntry{bpart[l], B * rownorm_bwd_chunks(n), ct, g.c0[gi], g.w[gi],
-                                                       st->b_off[l]};
-        }
+        // bias gradients: column sums of dU go straight into each graph's (zeroed) slab row with float atomics
+        GroupPtrs dbias{};
+        dbias.p[0] = li.e->b_off[l] >= 0 ? slabs + li.e->b_off[l] : nullptr;
+        dbias.p[1] = (li.a && li.a->b_off[l] >= 0) ? slabs + li.a->b_off[l] : nullptr;
+        dbias.ld[0] = dbias.ld[1] = (int)gstride;
+        rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, part, g, dUj, ct, &dbias, B, n, !last, has_bn,
+                    1);
         // G = A^T dU (+ dU)
         aggregate(q, io.adj, dUj, ct, Gj, ct, B, n, ct, true, 0.f);
         if (add_self) axpy(q, Gj, dUj, 1.f, (long)B * n * ct);
@@ -518,7 +516,6 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     // ---- workspace walk
     size_t maxPU = 0, maxPart = 0, maxSK = 0, maxMeans = 0;
     LevelGrad gr[DP_MAX_LEVELS + 1]{};
-    float* bpart[DP_MAX_LEVELS + 1][DP_MAX_LAYERS];
     // zero-initialised gradient accumulators are carved from ONE block (one memset)
     const size_t zero_begin = q.ws_off;
     for (int j = 0; j <= P; ++j) {
@@ -537,10 +534,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
         if ((size_t)li.n * li.G * 2 > maxMeans) maxMeans = (size_t)li.n * li.G * 2;
         if (li.a && rows * li.K > maxSK) maxSK = rows * li.K;
         gr[j].dZa = li.a ? q.alloc<float>(rows * li.Da) : nullptr;
-        for (int l = 0; l < li.L; ++l)
-            bpart[j][l] = q.alloc<float>((size_t)B * rownorm_bwd_chunks(li.n) * li.ctot[l]);
     }
-    BiasReduceTable btab{};
     float* Pj = q.alloc<float>(maxPU);
     float* dUj = q.alloc<float>(maxPU);
     float* Gj = q.alloc<float>(maxPU);
@@ -566,7 +560,8 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     // every entry of `grads` is written below (weights: slab reduce / direct GEMM; biases: reduce_bias /
     // column sums), so no memset of it is needed
     q.zero(q.ws + zero_begin, zero_end - zero_begin);
-    if (KS > 1) q.zero(slabs, (size_t)B * KS * c.n_graph_params * sizeof(float));   // unused split-K rows must be 0
+    // the slabs receive atomic adds (bias sums) and leave split-K rows unused: zero them once per backward
+    q.zero(slabs, (size_t)B * KS * c.n_graph_params * sizeof(float));
     // ---- pred_model backward
     for (int i = c.n_pred - 1; i >= 0; --i) {
         const int din = c.pred_dims[i], dout = c.pred_dims[i + 1];
@@ -645,13 +640,12 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
                       (long)n * K, 0, (long)n * li.Da, false, false, 1.f, 0.f, 0);
             }
             if (c.assign_pred_b_off[j] >= 0)
-                colsum_batched(q, dlog, K, (long)n * K, n, K, slabs + c.assign_pred_b_off[j], slab_stride * KS, B);
+                colsum_batched(q, dlog, K, (long)n * K, n, K, slabs + c.assign_pred_b_off[j], slab_stride * KS, B,
+                               n >= 256 ? 8 : 1);
         }
-        level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, KS, Pj, dUj, Gj, part, part_b, bpart[j],
-                       btab);
+        level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, KS, Pj, dUj, Gj, part, part_b);
     }
     reduce_slabs(q, slabs, slab_stride, B * KS, grads, c.n_graph_params, 0);
-    reduce_bias(q, btab, grads);
     return q.err;
 }
 

@@ -220,7 +220,9 @@ struct RownormBwdArgs {
     RowGroups g;
     float* dU;
     int ldu;
-    float* bpart;         // [B, chunks, ldu] column sums of dU per (graph, row chunk) or null
+    GroupPtrs dbias;      // per group: this layer's bias-gradient slab (row of graph 0; graphs are dbias.ld apart)
+                          // — column sums of dU are ADDED with float atomics (the slabs are zeroed per backward)
+    int want_bias;
     int B, n;
     int rows_per_chunk;
     int has_relu, has_bn, normalize;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
     const int ct = a.g.c0[a.g.G - 1] + a.g.w[a.g.G - 1];
     // each 16-lane team owns one row of the LDS accumulator (no atomics: lane c owns columns c, c+16, ...)
     float* mysum = colsum + team * ct;
-    if (a.bpart) {
+    if (a.want_bias) {
         for (int c = threadIdx.x; c < 16 * ct; c += 256) colsum[c] = 0.f;
         __syncthreads();
     }
@@ -283,71 +285,54 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
             if (a.has_relu) d = yy > 0.f ? d : 0.f;
             const float v = project ? inv * (d - yy * dot) : inv * d;
             du[c] = v;
-            if (a.bpart) mysum[a.g.c0[g] + c] += v;
+            if (a.want_bias) mysum[a.g.c0[g] + c] += v;
         }
     }
-    if (a.bpart) {
+    if (a.want_bias) {
         __syncthreads();
-        float* out = a.bpart + ((long)b * gridDim.x + chunk) * a.ldu;
         for (int c = threadIdx.x; c < ct; c += 256) {
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) t += colsum[k * ct + c];
-            out[c] = t;
+            const int g = (a.g.G == 2 && c >= a.g.c0[1]) ? 1 : 0;
+            float* dst = a.dbias.p[g];
+            if (dst) atomicAdd(dst + (long)b * a.dbias.ld[g] + (c - a.g.c0[g]), t);
         }
     }
 }
 int rownorm_bwd_chunks(int n) { return (n + 7) / 8; }
 void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const float* invn, const float* stats,
-                 const float* part2, RowGroups g, float* dU, int ldu, float* bpart, int B, int n, int has_relu,
-                 int has_bn, int normalize) {
+                 const float* part2, RowGroups g, float* dU, int ldu, const GroupPtrs* dbias, int B, int n,
+                 int has_relu, int has_bn, int normalize) {
     if (!q.ok()) return;
-    RownormBwdArgs a{dx, xhat, y, invn, stats, part2, g, dU, ldu, bpart, B, n, 8, has_relu, has_bn, normalize};
-    const int ct = g.c0[g.G - 1] + g.w[g.G - 1];
-    hipLaunchKernelGGL(k_rownorm_bwd, dim3(rownorm_bwd_chunks(n), B), dim3(256),
-                       bpart ? 16 * ct * sizeof(float) : 0, q.stream, a);
-    q.check_launch("rownorm_bwd");
-}
-
-// Bias gradients: grads[dst + c] = sum over (graph, chunk) rows of bpart[., c0 + c]   (one launch for all layers)
-__global__ __launch_bounds__(1024) void k_reduce_bias(BiasReduceTable t, float* grads) {
-    __shared__ float red[16][64];
-    const BiasReduceEntry& e = t.e[blockIdx.x];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
-    if (blockIdx.y * 64 >= e.w) return;
-    float s = 0.f;
-    if (c < e.w)
-        for (int r = rl; r < e.rows; r += 16) s += e.src[(long)r * e.ld + e.c0 + c];
-    red[rl][cl] = s;
-    __syncthreads();
-    if (rl == 0 && c < e.w) {
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v += red[k][cl];
-        grads[e.dst + c] = v;
+    GroupPtrs db{};
+    int want = 0;
+    if (dbias) {
+        db = *dbias;
+        want = (db.p[0] || db.p[1]) ? 1 : 0;
     }
-}
-void reduce_bias(Seq& q, const BiasReduceTable& t, float* grads) {
-    if (!q.ok() || t.count <= 0) return;
-    int maxw = 1;
-    for (int i = 0; i < t.count; ++i) maxw = t.e[i].w > maxw ? t.e[i].w : maxw;
-    hipLaunchKernelGGL(k_reduce_bias, dim3(t.count, (maxw + 63) / 64), dim3(1024), 0, q.stream, t, grads);
-    q.check_launch("reduce_bias");
+    RownormBwdArgs a{dx, xhat, y, invn, stats, part2, g, dU, ldu, db, want, B, n, 8, has_relu, has_bn, normalize};
+    const int ct = g.c0[g.G - 1] + g.w[g.G - 1];
+    hipLaunchKernelGGL(k_rownorm_bwd, dim3(rownorm_bwd_chunks(n), B), dim3(256), want ? 16 * ct * sizeof(float) : 0,
+                       q.stream, a);
+    q.check_launch("rownorm_bwd");
 }
 
 // ------------------------------------------------------------------ column sums
 // out[b, c] = sum_r X[b, r, c]    (bias gradients; deterministic)
 __global__ __launch_bounds__(1024) void k_colsum_batched(const float* X, int ldx, long strideX, int rows, int cols,
-                                                         float* out, long strideOut) {
+                                                         float* out, long strideOut, int atomic) {
     __shared__ float red[16][64];
     const int b = blockIdx.y;
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
+    // blockIdx.z splits the rows (atomic mode only)
+    const int per = (rows + gridDim.z - 1) / gridDim.z;
+    const int rbeg = blockIdx.z * per, rend = min(rows, rbeg + per);
     float s = 0.f;
     if (c < cols) {
         const float* x = X + (long)b * strideX + c;
-        for (int r = rl; r < rows; r += 16) s += x[(long)r * ldx];
+        for (int r = rbeg + rl; r < rend; r += 16) s += x[(long)r * ldx];
     }
     red[rl][cl] = s;
     __syncthreads();
@@ -355,14 +340,17 @@ __global__ __launch_bounds__(1024) void k_colsum_batched(const float* X, int ldx
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][cl];
-        out[(long)b * strideOut + c] = t;
+        if (atomic) atomicAdd(out + (long)b * strideOut + c, t);
+        else out[(long)b * strideOut + c] = t;
     }
 }
+// rowsplit > 1: the rows are cut into `rowsplit` ranges that ADD into `out` with float atomics (out pre-zeroed)
 void colsum_batched(Seq& q, const float* X, int ldx, long strideX, int rows, int cols, float* out, long strideOut,
-                    int batch) {
+                    int batch, int rowsplit) {
     if (!q.ok() || cols <= 0 || batch <= 0) return;
-    hipLaunchKernelGGL(k_colsum_batched, dim3((cols + 63) / 64, batch), dim3(1024), 0, q.stream, X, ldx, strideX,
-                       rows, cols, out, strideOut);
+    if (rowsplit < 1) rowsplit = 1;
+    hipLaunchKernelGGL(k_colsum_batched, dim3((cols + 63) / 64, batch, rowsplit), dim3(1024), 0, q.stream, X, ldx,
+                       strideX, rows, cols, out, strideOut, rowsplit > 1 ? 1 : 0);
     q.check_launch("colsum_batched");
 }
 
@@ -595,17 +583,27 @@ void ce_bwd(Seq& q, const float* prob, const long long* label, const float* dlos
 
 // ------------------------------------------------------------------ slab reduce
 // out[p] (+)= sum_b slabs[b, p]   — per-graph parameter-gradient slabs -> the flat gradient buffer
-__global__ void k_reduce_slabs(const float* slabs, long stride, int B, float* out, long count, int accumulate) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+__global__ __launch_bounds__(1024) void k_reduce_slabs(const float* slabs, long stride, int B, float* out,
+                                                       long count, int accumulate) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += slabs[(long)b * stride + i];
-    out[i] = accumulate ? out[i] + s : s;
+    if (i < count)
+        for (int b = rl; b < B; b += 16) s += slabs[(long)b * stride + i];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && i < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        out[i] = accumulate ? out[i] + t : t;
+    }
 }
 void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, long count, int accumulate) {
     if (!q.ok() || count <= 0) return;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((count + 255) / 256), dim3(256), 0, q.stream, slabs, stride, B, out,
-                       count, accumulate);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((count + 63) / 64), dim3(1024), 0, q.stream, slabs, stride, B, out, count,
+                       accumulate);
     q.check_launch("reduce_slabs");
 }
 
