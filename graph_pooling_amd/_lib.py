@@ -59,6 +59,11 @@ _PROTOS = {
     "dp_sizeof_encoder_cfg": (_Z, []),
     "dp_bgemm_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _F, _I, _P]),
     "dp_adj_aggregate": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "dp_adj_pack_ld": (_I, [_I]),
+    "dp_adj_pack_bytes": (_Z, [_I, _I]),
+    "dp_adj_pack": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "dp_adj_aggregate_packed_workspace_bytes": (_Z, [_I, _I, _I]),
+    "dp_adj_aggregate_packed": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     "dp_gcn_layer_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "dp_gcn_layer_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "dp_gcn_layer_bwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),

@@ -35,6 +35,13 @@ struct AggArgs {
     int n, C;
     int tiles;           // row tiles per graph
     int dbg;             // ablation switches (DP_AGG_DEBUG): 1 no multiply loop, 2 no panel DMA, 4 no V loads
+    // exact-bf16 fast path (binary adjacency): packed op(A) [B, n, pk_ld] bf16, the 3-plane bf16 split of V
+    // and the device flag written by k_adj_pack (0 = every entry of A is bf16-exact)
+    const unsigned short* pk_A;
+    int pk_ld;
+    const int* pk_flag;
+    const unsigned short* Vs;   // [B][3][CT][K8][16][8]
+    int vs_k8;
     // plain epilogue
     float* U;            // [B, n, C] (ldu) or null
     int ldu;
@@ -64,36 +71,18 @@ __device__ inline float agg_team_sum(float v) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// exact-fp32 accumulate: acc += op(A)[r0.., :] · V   (any adjacency values)
 template <bool TRANS, int CT, int AGG_RT>
-__global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
+__device__ __forceinline__ void accumulate_fp32(const AggArgs& a, int b, int r0, float* lds,
+                                                f32x4 (&acc)[AGG_RT / 16][CT]) {
     constexpr int MI = AGG_RT / 16;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // XCD-aware work mapping: consecutive block ids are dealt round-robin over the 8 XCDs (each with its own
-    // L2), so block id -> work id is remapped (bijectively) to give every XCD one CONTIGUOUS run of
-    // (graph, row tile) items: the 16 row tiles of a graph then share one L2 for their V operand instead of
-    // fetching it into all eight (measured: 32 MB -> ~22 MB of fabric reads per DD launch).
-    const int nwg = gridDim.x, tiles = a.tiles;
-    int wid;
-    {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int qd = nwg >> 3, rm = nwg & 7;
-        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
-    }
-    const int b = wid / tiles;
-    const int r0 = (wid % tiles) * AGG_RT;
     const int n = a.n;
     const float* A = a.A + (long)b * n * n;
     const float* V = a.V + (long)b * n * a.ldv;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
-
-    f32x4 acc[MI][CT];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < CT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     const int kpanel = TRANS ? n : min(n, AGG_KP);
     const int segs = (kpanel + 255) / 256;
     const int ldp = TRANS ? AGG_RT : segs * 256 + 4;  // NN: = 4 (mod 64)
@@ -192,6 +181,119 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
         __syncthreads();                               // panel may be overwritten (next K panel / reduction)
     }
 
+}
+
+typedef short agg_s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 agg_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline void dma16_raw(const void* src, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// exact-bf16 accumulate for bf16-representable adjacency (0/1 graphs): acc += Abf[r0.., :] · (V_hi + V_mid + V_lo).
+// Every product of two bf16 numbers is exact in fp32 and hi+mid+lo reproduces the fp32 V bit for bit, so the
+// result is the same fp32-accumulated sum of exact products the fp32 MFMA gives — at 16/3 of its rate and half
+// the adjacency bytes.  The packed operand is already oriented (A or A^T), so there is one loop for both passes.
+// LDS panel image: [RT][ldp] bf16, ldp = 8 (mod 128)  -> ds_read_b128 A-fragment reads are conflict-free.
+template <int CT, int AGG_RT>
+__device__ __forceinline__ void accumulate_bf16(const AggArgs& a, int b, int r0, float* ldsf,
+                                                f32x4 (&acc)[AGG_RT / 16][CT]) {
+    constexpr int MI = AGG_RT / 16;
+    unsigned short* lds = reinterpret_cast<unsigned short*>(ldsf);
+    const int n = a.n, np = a.pk_ld;
+    const unsigned short* A = a.pk_A + (long)b * n * np;
+    const int K8 = a.vs_k8;
+    const unsigned short* Vs = a.Vs + (long)b * 3 * CT * K8 * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int segs = (n + 511) / 512;
+    const int ldp = segs * 512 + 8;
+    const int steps = (n + 31) / 32;
+
+    agg_s16x8 f0[3][CT], f1[3][CT];
+    auto load_b = [&](int step, agg_s16x8 (&dst)[3][CT]) {
+        const int st = min(step, steps - 1);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int cb = 0; cb < CT; ++cb)
+                dst[p][cb] = *reinterpret_cast<const agg_s16x8*>(
+                    Vs + ((((long)p * CT + cb) * K8 + st * 4 + kq) * 16 + l15) * 8);
+    };
+    auto mma = [&](int step, const agg_s16x8 (&bf)[3][CT]) {
+        agg_s16x8 av[MI];
+#pragma unroll
+        for (int rb = 0; rb < MI; ++rb)
+            av[rb] = *reinterpret_cast<const agg_s16x8*>(lds + (rb * 16 + l15) * ldp + step * 32 + kq * 8);
+#pragma unroll
+        for (int p = 2; p >= 0; --p)      // lo, mid, hi: small terms first
+#pragma unroll
+            for (int rb = 0; rb < MI; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < CT; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(agg_bf16x8, av[rb]),
+                                                                          __builtin_bit_cast(agg_bf16x8, bf[p][cb]),
+                                                                          acc[rb][cb], 0, 0, 0);
+    };
+    load_b(wave, f0);
+    load_b(wave + 4, f1);
+    // rows r0..r0+RT-1 of the packed operand: pieces (row i, segment s) of 512 bf16 = 1 KiB
+    const int pieces = AGG_RT * segs;
+    for (int pc = wave; pc < pieces; pc += 4) {
+        const int i = pc / segs, s = pc % segs;
+        const int row = min(r0 + i, n - 1);
+        const int col = min(s * 512 + lane * 8, np - 8);   // clamp: finite duplicates, they meet zero V planes
+        dma16_raw(A + (long)row * np + col, lds + i * ldp + s * 512);
+    }
+    __syncthreads();
+    for (int step = wave; step < steps; step += 8) {
+        mma(step, f0);
+        if (step + 4 < steps) {
+            load_b(step + 8, f0);
+            mma(step + 4, f1);
+            load_b(step + 12, f1);
+        }
+    }
+    __syncthreads();
+}
+
+template <bool TRANS, int CT, int AGG_RT>
+__global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
+    constexpr int MI = AGG_RT / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // XCD-aware work mapping: consecutive block ids are dealt round-robin over the 8 XCDs (each with its own
+    // L2), so block id -> work id is remapped (bijectively) to give every XCD one CONTIGUOUS run of
+    // (graph, row tile) items: the 16 row tiles of a graph then share one L2 for their V operand instead of
+    // fetching it into all eight (measured: 32 MB -> ~22 MB of fabric reads per DD launch).
+    const int nwg = gridDim.x, tiles = a.tiles;
+    int wid;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qd = nwg >> 3, rm = nwg & 7;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int b = wid / tiles;
+    const int r0 = (wid % tiles) * AGG_RT;
+    const int n = a.n;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+
+    f32x4 acc[MI][CT];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bool use_bf16 = a.pk_A != nullptr && __builtin_amdgcn_readfirstlane(*a.pk_flag) == 0;
+    if (use_bf16)
+        accumulate_bf16<CT, AGG_RT>(a, b, r0, lds, acc);
+    else
+        accumulate_fp32<TRANS, CT, AGG_RT>(a, b, r0, lds, acc);
+
     // ---------------- cross-wave reduction through LDS: red[wave][32][CTP]
     constexpr int CTP = CT * 16 + 1;
     float* red = lds;
@@ -215,7 +317,16 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
                 *u = (a.beta != 0.f) ? s + a.beta * (*u) : s;
             }
         } else {
-            tile[r * CTP + c] = s;
+            // fold bias (+ the add_self operand) in here, with ONE round of coalesced global loads, so the
+            // row passes below read LDS only
+            float u = s;
+            if (c < a.C) {
+                const int g = (a.g.G == 2 && c >= a.g.c0[1]) ? 1 : 0;
+                const float* bias = a.bias.p[g];
+                if (bias) u += bias[c - a.g.c0[g]];
+                if (a.P && r0 + r < n) u += a.P[((long)b * n + r0 + r) * a.ldv + c];
+            }
+            tile[r * CTP + c] = u;
         }
     }
     if (a.U) return;
@@ -230,24 +341,14 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
         const long row = (long)b * n + node;
         const int c0 = a.g.c0[g], w = a.g.w[g];
         const float* u = tile + r * CTP + c0;
-        const float* p = a.P ? a.P + row * a.ldv + c0 : nullptr;
-        const float* bias = a.bias.p[g];
         float ss = 0.f;
-        for (int c = tl; c < w; c += 16) {
-            float v = u[c];
-            if (p) v += p[c];
-            if (bias) v += bias[c];
-            ss += v * v;
-        }
+        for (int c = tl; c < w; c += 16) ss += u[c] * u[c];
         ss = agg_team_sum(ss);
         const float inv = a.normalize ? 1.f / fmaxf(sqrtf(ss), AGG_L2_EPS) : 1.f;
         float* y = a.yout.p[g] + row * a.yout.ld[g];
         float s1 = 0.f;
         for (int c = tl; c < w; c += 16) {
-            float v = u[c];
-            if (p) v += p[c];
-            if (bias) v += bias[c];
-            v *= inv;
+            const float v = u[c] * inv;
             y[c] = v;
             s1 += a.stats_mode == 1 ? fmaxf(v, 0.f) : v;
         }
@@ -257,10 +358,7 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
             const float mean = s1 / (float)w;
             float m2 = 0.f;
             for (int c = tl; c < w; c += 16) {
-                float v = u[c];
-                if (p) v += p[c];
-                if (bias) v += bias[c];
-                v *= inv;
+                float v = u[c] * inv;
                 if (a.stats_mode == 1) v = fmaxf(v, 0.f);
                 v -= mean;
                 m2 += v * v;
@@ -279,7 +377,10 @@ static size_t agg_lds_bytes(bool trans, int n, int CT, int RT) {
     const int segs = (kpanel + 255) / 256;
     const size_t panel = trans ? (size_t)((n + 15) / 16) * 16 * RT : (size_t)RT * (segs * 256 + 4);
     const size_t red = (size_t)5 * RT * (CT * 16 + 1);
-    return (panel > red ? panel : red) * sizeof(float);
+    const size_t pk = ((size_t)RT * (((n + 511) / 512) * 512 + 8) * 2 + 3) / 4;     // bf16 panel, in floats
+    size_t m = panel > red ? panel : red;
+    if (pk > m) m = pk;
+    return m * sizeof(float);
 }
 // 16-row tiles when 32-row tiles would leave the chip with < 2 workgroups per CU (small batches): twice the
 // workgroups, four co-resident per CU, so one workgroup's panel burst overlaps its neighbours' multiplies.
@@ -326,10 +427,107 @@ static void dispatch_ct(Seq& q, const AggArgs& a, int B) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_adj_pack: one pass over the fp32 adjacency -> bf16 copies of A and A^T (rows padded to `ld` = a multiple
+// of 8 elements, zero filled) + a device flag that ends up non-zero iff some entry is NOT exactly
+// representable in bf16 (low 16 mantissa bits set).  0/1 adjacency (graph_sampler.py:26) is always exact.
+__global__ __launch_bounds__(256) void k_adj_pack(const float* A, unsigned short* P, unsigned short* Pt, int* flag,
+                                                  int n, int ld) {
+    __shared__ unsigned short tile[64][66];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const float* Ab = A + (long)b * n * n;
+    unsigned short* Pb = P + (long)b * n * ld;
+    unsigned short* Ptb = Pt + (long)b * n * ld;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    bool bad = false;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        unsigned bits = 0;
+        if (r < n && c < n) bits = __float_as_uint(Ab[(long)r * n + c]);
+        bad |= (bits & 0xFFFFu) != 0;
+        const unsigned short h = (unsigned short)(bits >> 16);
+        tile[i][tx] = h;
+        if (r < n && c < ld) Pb[(long)r * ld + c] = h;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int r = c0 + i, c = r0 + tx;       // transposed tile
+        if (r < n && c < ld) Ptb[(long)r * ld + c] = tile[tx][i];
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int* flag, int B, int n, int ld) {
+    if (!q.ok()) return;
+    q.zero(flag, 256);
+    const int t = (ld + 63) / 64;
+    hipLaunchKernelGGL(k_adj_pack, dim3(t, (n + 63) / 64, B), dim3(256), 0, q.stream, A, P, Pt, flag, n, ld);
+    q.check_launch("adj_pack");
+}
+int adj_pack_ld(int n) { return (n + 7) & ~7; }
+bool adj_pack_supported(int n, int C) {
+    // worth it only for big levels; the packed rows must be 16-byte multiples
+    return n >= 128 && C >= 1 && C <= 128 &&
+           ((size_t)32 * (((n + 511) / 512) * 512 + 8) * 2 <= 150 * 1024);
+}
+
+// k_split3: V [B, n, C] fp32 -> three bf16 planes hi, mid, lo with hi + mid + lo == V exactly, in the layout
+// the bf16 MFMA B-operand wants: Vs[b][plane][cb][k8][c][j] = plane(V[b][8*k8 + j][16*cb + c]), zero padded in k
+// (to a multiple of 32) and c (to 16*CT).  One 16-byte store per (plane, k8, c).
+__device__ inline unsigned short bf16_rn(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7FFFu + ((u >> 16) & 1u);     // round to nearest even (inputs are finite)
+    return (unsigned short)(u >> 16);
+}
+__global__ __launch_bounds__(256) void k_split3(const float* V, int ldv, unsigned short* Vs, int n, int C, int CT,
+                                                int K8) {
+    const int b = blockIdx.y;
+    const int item = blockIdx.x * 256 + threadIdx.x;          // (cb, k8, c)
+    if (item >= CT * K8 * 16) return;
+    const int c = item & 15, k8 = (item >> 4) % K8, cb = (item >> 4) / K8;
+    const int col = cb * 16 + c;
+    agg_s16x8 hi, mid, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k8 * 8 + j;
+        float v = 0.f;
+        if (k < n && col < C) v = V[((long)b * n + k) * ldv + col];
+        const unsigned short h = bf16_rn(v);
+        const float r1 = v - __uint_as_float((unsigned)h << 16);
+        const unsigned short m = bf16_rn(r1);
+        const float r2 = r1 - __uint_as_float((unsigned)m << 16);
+        const unsigned short l = bf16_rn(r2);
+        hi[j] = (short)h; mid[j] = (short)m; lo[j] = (short)l;
+    }
+    unsigned short* base = Vs + (long)b * 3 * CT * K8 * 128;
+    *reinterpret_cast<agg_s16x8*>(base + ((((long)0 * CT + cb) * K8 + k8) * 16 + c) * 8) = hi;
+    *reinterpret_cast<agg_s16x8*>(base + ((((long)1 * CT + cb) * K8 + k8) * 16 + c) * 8) = mid;
+    *reinterpret_cast<agg_s16x8*>(base + ((((long)2 * CT + cb) * K8 + k8) * 16 + c) * 8) = lo;
+}
+size_t split3_elems(int B, int n, int C) {
+    const int CT = (C + 15) / 16, K8 = ((n + 31) / 32) * 4;
+    return (size_t)B * 3 * CT * K8 * 128;
+}
+static void split3(Seq& q, const float* V, int ldv, unsigned short* Vs, int B, int n, int C) {
+    const int CT = (C + 15) / 16, K8 = ((n + 31) / 32) * 4;
+    hipLaunchKernelGGL(k_split3, dim3((CT * K8 * 16 + 255) / 256, B), dim3(256), 0, q.stream, V, ldv, Vs, n, C, CT, K8);
+    q.check_launch("split3");
+}
+
+static void fill_packed(AggArgs& a, const PackedAdj* pk, bool trans, const unsigned short* vs, int n) {
+    a.pk_A = trans ? pk->At : pk->A;
+    a.pk_ld = pk->ld;
+    a.pk_flag = pk->flag;
+    a.Vs = vs;
+    a.vs_k8 = ((n + 31) / 32) * 4;
+}
+
 // U[b] (ldu) = op(A[b]) V[b] (+ beta U[b]);  falls back to the generic GEMM for shapes the panel kernel
-// does not take (n not a multiple of 4, C > 128, unaligned A).
+// does not take (n not a multiple of 4, C > 128, unaligned A).  With `pk` (a packed copy of A from adj_pack) and a
+// scratch buffer `vs` (split3_elems) the bf16 path is taken when the device flag says A is bf16-exact.
 void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ldu, int B, int n, int C, bool trans,
-               float beta) {
+               float beta, const PackedAdj* pk, unsigned short* vs) {
     if (!q.ok()) return;
     if (!aggregate_supported(A, n, C, trans)) {
         bgemm(q, A, V, U, nullptr, B, n, C, n, n, ldv, ldu, (long)n * n, (long)n * ldv, (long)n * ldu, trans, false,
@@ -338,6 +536,10 @@ void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ld
     }
     AggArgs a{};
     a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = U; a.ldu = ldu; a.beta = beta;
+    if (pk && vs && adj_pack_supported(n, C)) {
+        split3(q, V, ldv, vs, B, n, C);
+        fill_packed(a, pk, trans, vs, n);
+    }
     if (trans) dispatch_ct<true>(q, a, B); else dispatch_ct<false>(q, a, B);
     q.check_launch("aggregate");
 }
@@ -346,7 +548,7 @@ void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ld
 // apply_bn partial statistics.  Returns false (nothing launched) when the shape needs the generic path.
 bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, const float* P, GroupCPtrs bias,
                            RowGroups g, GroupPtrs yout, float* invn, float* part, int B, int n, int normalize,
-                           int stats_mode) {
+                           int stats_mode, const PackedAdj* pk, unsigned short* vs) {
     const int C = g.c0[g.G - 1] + g.w[g.G - 1];
     if (!aggregate_supported(A, n, C, false)) return false;
     if (!q.ok()) return true;
@@ -354,6 +556,10 @@ bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, cons
     a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = nullptr;
     a.P = P; a.bias = bias; a.g = g; a.yout = yout; a.invn = invn; a.part = part;
     a.normalize = normalize; a.stats_mode = stats_mode;
+    if (pk && vs && adj_pack_supported(n, C)) {
+        split3(q, V, ldv, vs, B, n, C);
+        fill_packed(a, pk, false, vs, n);
+    }
     dispatch_ct<false>(q, a, B);
     q.check_launch("aggregate_rownorm_fwd");
     return true;

@@ -245,6 +245,32 @@ int dp_adj_aggregate(const float* adj, const float* V, int ldv, float* U, int ld
     return q.err;
 }
 
+int dp_adj_pack_ld(int n) { return adj_pack_ld(n); }
+size_t dp_adj_pack_bytes(int B, int n) { return (size_t)B * n * adj_pack_ld(n) * sizeof(unsigned short); }
+int dp_adj_pack(const float* adj, void* packed, void* packed_t, int* flag, int B, int n, void* stream) {
+    NOTNULL(adj); NOTNULL(packed); NOTNULL(packed_t); NOTNULL(flag);
+    NONNEG(B); NONNEG(n);
+    Seq q(STREAM(stream), nullptr, 0);
+    adj_pack(q, adj, (unsigned short*)packed, (unsigned short*)packed_t, flag, B, n, adj_pack_ld(n));
+    return q.err;
+}
+size_t dp_adj_aggregate_packed_workspace_bytes(int B, int n, int C) {
+    return split3_elems(B, n, C) * sizeof(unsigned short) + 512;
+}
+int dp_adj_aggregate_packed(const float* adj, const void* packed, const void* packed_t, const int* flag,
+                            const float* V, int ldv, float* U, int ldu, int B, int n, int C, int trans, float beta,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    NOTNULL(adj); NOTNULL(packed); NOTNULL(packed_t); NOTNULL(flag); NOTNULL(V); NOTNULL(U);
+    NONNEG(B); NONNEG(n); NONNEG(C);
+    DP_CHECK_ARG(ldv >= C && ldu >= C, "ldv=%d/ldu=%d smaller than C=%d", ldv, ldu, C);
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    unsigned short* vs = q.alloc<unsigned short>(split3_elems(B, n, C));
+    if (q.err) return q.err;
+    PackedAdj pk{(const unsigned short*)packed, (const unsigned short*)packed_t, adj_pack_ld(n), flag};
+    aggregate(q, adj, V, ldv, U, ldu, B, n, C, trans != 0, beta, &pk, vs);
+    return q.err;
+}
+
 size_t dp_gcn_layer_workspace_bytes(int B, int n, int Fin, int Fout) {
     size_t f = sized([&](Seq& q) { gcn_layer_fwd_seq(q, 0, Fin, 0, 0, 0, 0, Fout, 0, B, n, Fin, Fout, 0); });
     size_t b = sized([&](Seq& q) {

@@ -156,11 +156,21 @@ void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, lo
 void axpy(Seq& q, float* y, const float* x, float a, long count);
 
 // (dp_agg.hip) adjacency-panel aggregation
+struct PackedAdj {               // written by adj_pack: bf16 copies of A and A^T + the exactness flag
+    const unsigned short* A;     // [B, n, ld]
+    const unsigned short* At;    // [B, n, ld]
+    int ld;                      // adj_pack_ld(n)
+    const int* flag;             // device int: 0 = every entry of A is exactly representable in bf16
+};
+void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int* flag, int B, int n, int ld);
+int adj_pack_ld(int n);
+bool adj_pack_supported(int n, int C);
+size_t split3_elems(int B, int n, int C);
 void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ldu, int B, int n, int C, bool trans,
-               float beta);
+               float beta, const PackedAdj* pk = nullptr, unsigned short* vs = nullptr);
 bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, const float* P, GroupCPtrs bias,
                            RowGroups g, GroupPtrs yout, float* invn, float* part, int B, int n, int normalize,
-                           int stats_mode);
+                           int stats_mode, const PackedAdj* pk = nullptr, unsigned short* vs = nullptr);
 
 // (dp_small.hip) one-workgroup-per-graph GCN layers of a pooled level (n <= 64)
 bool small_level_supported(int B, int n, int din, int dout);

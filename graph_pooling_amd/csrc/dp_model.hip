@@ -87,6 +87,10 @@ struct LevelSave {
     int* argmax;
 };
 struct SaveLayout {
+    unsigned short* pkA;     // bf16 copy of the level-0 adjacency [B, N, pk_ld] (null: not packed)
+    unsigned short* pkAt;    // ... of its transpose
+    int* pk_flag;
+    int pk_ld;
     LevelSave lv[DP_MAX_LEVELS + 1];
     float* feat;
     float* hid[DP_MAX_PRED + 2];
@@ -103,6 +107,13 @@ SaveLayout layout_save(const dp_encoder_cfg& c, void* base) {
     SaveLayout s{};
     Bump b{(char*)base, 0};
     const size_t B = c.B;
+    if (adj_pack_supported(c.N, 1)) {
+        s.pk_ld = adj_pack_ld(c.N);
+        s.pkA = b.take<unsigned short>(B * c.N * s.pk_ld);
+        s.pkAt = b.take<unsigned short>(B * c.N * s.pk_ld);
+        s.pk_flag = b.take<int>(64);
+        if (!base) s.pkA = s.pkAt = reinterpret_cast<unsigned short*>(1);   // dry run: "packing enabled" marker
+    }
     for (int j = 0; j <= c.num_pooling; ++j) {
         const LevelInfo li = level_info(c, j);
         LevelSave& lv = s.lv[j];
@@ -239,7 +250,8 @@ void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const Level
 }
 
 void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
-                   const float* params, float* Pj, float* Uj, float* part, float* part_b) {
+                   const float* params, float* Pj, float* Uj, float* part, float* part_b, const PackedAdj* pk,
+                   unsigned short* vs) {
     const int B = c.B, n = li.n;
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
@@ -282,7 +294,7 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
         const int stats_mode = (!last && bn) ? 1 : 0;
         // aggregation + GraphConv tail in one launch when the panel kernel takes the shape
         if (!aggregate_rownorm_fwd(q, io.adj, Pj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn,
-                                   stats_mode ? part : nullptr, B, n, 1, stats_mode)) {
+                                   stats_mode ? part : nullptr, B, n, 1, stats_mode, pk, vs)) {
             bgemm(q, io.adj, Pj, Uj, nullptr, B, n, ct, n, n, ct, ct, (long)n * n, (long)n * ct, (long)n * ct, false,
                   false, 1.f, 0.f, 0);
             rownorm_fwd(q, Uj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn,
@@ -308,7 +320,7 @@ struct LevelGrad {
 
 void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
                     const float* params, const LevelGrad& gr, float* slabs, long slab_stride, int KS, float* Pj,
-                    float* dUj, float* Gj, float* part, float* part_b) {
+                    float* dUj, float* Gj, float* part, float* part_b, const PackedAdj* pk, unsigned short* vs) {
     const int B = c.B, n = li.n;
     const long gstride = slab_stride * KS;     // slab rows of one graph: KS split-K partials
     const int ks_level = n >= 256 ? KS : 1;
@@ -367,7 +379,7 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
         rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, part, g, dUj, ct, &dbias, B, n, !last, has_bn,
                     1);
         // G = A^T dU (+ dU)
-        aggregate(q, io.adj, dUj, ct, Gj, ct, B, n, ct, true, 0.f);
+        aggregate(q, io.adj, dUj, ct, Gj, ct, B, n, ct, true, 0.f, pk, vs);
         if (add_self) axpy(q, Gj, dUj, 1.f, (long)B * n * ct);
         {
             GemmDesc d[4];
@@ -421,7 +433,15 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
 
 struct Scratch {
     float *Pj, *Uj, *part, *part_b, *logits;
+    unsigned short* vs;      // 3-plane bf16 split of the current V operand (level 0, packed adjacency)
 };
+size_t vs_elems(const dp_encoder_cfg& c) {
+    if (!adj_pack_supported(c.N, 1)) return 64;
+    const LevelInfo li = level_info(c, 0);
+    int cm = li.cmax > li.K ? li.cmax : li.K;
+    if (cm > 128) cm = 128;
+    return split3_elems(c.B, c.N, cm) + 64;
+}
 
 // shared allocation walk for the forward (also used for sizing)
 Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
@@ -439,6 +459,7 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
     s.part = q.alloc<float>(maxPart);
     s.part_b = q.alloc<float>(maxPart);
     s.logits = q.alloc<float>(maxLog > 0 ? maxLog : 1);
+    s.vs = q.alloc<unsigned short>(vs_elems(c));
     return s;
 }
 
@@ -451,6 +472,10 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
     if (q.err) return q.err;
     const int B = c.B, P = c.num_pooling;
     const int ldfeat = c.pred_dims[0];
+    // one pass over the level-0 adjacency: bf16 copies of A and A^T + exactness flag (used by every later pass)
+    PackedAdj pk0{sv.pkA, sv.pkAt, sv.pk_ld, sv.pk_flag};
+    const PackedAdj* pkp = sv.pkA ? &pk0 : nullptr;
+    if (pkp) adj_pack(q, adj, sv.pkA, sv.pkAt, sv.pk_flag, B, c.N, sv.pk_ld);
     int featoff = 0;
     for (int j = 0; j <= P; ++j) {
         const LevelInfo li = level_info(c, j);
@@ -459,7 +484,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
         io.x0e = j == 0 ? x : sv.lv[j - 1].Xn;
         io.x0a = j == 0 ? assign_x : sv.lv[j - 1].Xn;
         io.adj = j == 0 ? adj : sv.lv[j - 1].An;
-        level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part, sc.part_b);
+        level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part, sc.part_b, j == 0 ? pkp : nullptr, sc.vs);
         const int* nn_j = (j == 0) ? num_nodes : nullptr;
         if (c.readout == 0) {
             const int rw = readout_width(c, li);
@@ -489,7 +514,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
                            (long)K * li.D, true, false, 1.f, 0.f, 0, 0, ksn > 1 ? 1 : 0};
                 bgemm_group(q, &d, 1, B, ksn);
             }
-            aggregate(q, io.adj, lv.S, K, lv.T, K, B, n, K, true, 0.f);
+            aggregate(q, io.adj, lv.S, K, lv.T, K, B, n, K, true, 0.f, j == 0 ? pkp : nullptr, sc.vs);
             {
                 GemmDesc d{lv.T, lv.S, lv.An, nullptr, K, K, n, K, K, K, (long)n * K, (long)n * K, (long)K * K, true,
                            false, 1.f, 0.f, 0, 0, ksn > 1 ? 1 : 0};
@@ -540,6 +565,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     float* Gj = q.alloc<float>(maxPU);
     float* part = q.alloc<float>(maxPart);
     float* part_b = q.alloc<float>(maxPart);
+    unsigned short* vs = q.alloc<unsigned short>(vs_elems(c));
     float* dS = q.alloc<float>(maxSK ? maxSK : 1);
     float* dlog = q.alloc<float>(maxSK ? maxSK : 1);
     float* V = q.alloc<float>(maxSK ? maxSK : 1);
@@ -556,6 +582,8 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     }
     if (q.err) return q.err;
     const long slab_stride = c.n_graph_params;
+    PackedAdj pk0{sv.pkA, sv.pkAt, sv.pk_ld, sv.pk_flag};
+    const PackedAdj* pkp = sv.pkA ? &pk0 : nullptr;
 
     // every entry of `grads` is written below (weights: slab reduce / direct GEMM; biases: reduce_bias /
     // column sums), so no memset of it is needed
@@ -624,7 +652,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
             // dS += T^T dA' ;  dS += A V
             bgemm(q, lv.T, dAn, dS, nullptr, B, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, false, 1.f,
                   1.f, 0);
-            aggregate(q, io.adj, V, K, dS, K, B, n, K, false, 1.f);
+            aggregate(q, io.adj, V, K, dS, K, B, n, K, false, 1.f, j == 0 ? pkp : nullptr, vs);
             if (gr[j].dAdj)   // dA_j += (S dA') S^T
                 bgemm(q, V2, lv.S, gr[j].dAdj, nullptr, B, n, n, K, K, K, n, (long)n * K, (long)n * K, (long)n * n, false,
                       true, 1.f, 1.f, 0);
@@ -643,7 +671,8 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
                 colsum_batched(q, dlog, K, (long)n * K, n, K, slabs + c.assign_pred_b_off[j], slab_stride * KS, B,
                                n >= 256 ? 8 : 1);
         }
-        level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, KS, Pj, dUj, Gj, part, part_b);
+        level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, KS, Pj, dUj, Gj, part, part_b,
+                       j == 0 ? pkp : nullptr, vs);
     }
     reduce_slabs(q, slabs, slab_stride, B * KS, grads, c.n_graph_params, 0);
     return q.err;

@@ -66,6 +66,20 @@ int dp_bgemm_f32(const float* A, const float* B, float* C, const float* bias, in
 int dp_adj_aggregate(const float* adj, const float* V, int ldv, float* U, int ldu, int B, int n, int C,
                      int trans, float beta, void* stream);
 
+/* Packed adjacency (the reference multiplies the same fp32 adjacency 12 times per step, encoders.py:965,1279,
+ * 1311).  dp_adj_pack makes ONE pass over adj [B,n,n] and writes bf16 copies of A and A^T (rows padded to
+ * dp_adj_pack_ld(n) elements) plus a device flag that is 0 iff every entry is exactly representable in bf16
+ * (always true for the 0/1 adjacency of graph_sampler.py:26).  dp_adj_aggregate_packed then computes the same
+ * U = op(adj)·V with V split exactly into three bf16 planes (fp32-grade result, bf16 MFMA rate, half the
+ * adjacency bytes) when the flag is 0, and with the fp32 loop otherwise — decided on the device, no sync. */
+int dp_adj_pack_ld(int n);
+size_t dp_adj_pack_bytes(int B, int n);            /* bytes of ONE packed copy */
+int dp_adj_pack(const float* adj, void* packed, void* packed_t, int* flag, int B, int n, void* stream);
+size_t dp_adj_aggregate_packed_workspace_bytes(int B, int n, int C);
+int dp_adj_aggregate_packed(const float* adj, const void* packed, const void* packed_t, const int* flag,
+                            const float* V, int ldv, float* U, int ldu, int B, int n, int C, int trans, float beta,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ A1  GraphConv
  * y = l2norm((adj @ x [+ x]) @ W + b)   — GraphConv.forward, encoders.py:962-974.
  * x [B,n,Fin] (ldx), adj [B,n,n], W [Fin,Fout], bias [Fout] or NULL, y [B,n,Fout] (ldy),

@@ -102,6 +102,66 @@ def test_adj_aggregate_padding_is_inert(lib):
     assert float(U[:, 30:].abs().max()) == 0.0
 
 
+# ------------------------------------------------------------------ packed (bf16-exact) adjacency path
+def _packed_aggregate(lib, adj, V, C, trans, beta, U0):
+    B, n = adj.shape[0], adj.shape[1]
+    ad, Vd, Ud = dev(adj), dev(V), dev(U0)
+    nb = lib.dp_adj_pack_bytes(B, n)
+    pk = torch.empty(nb, device="cuda", dtype=torch.uint8)
+    pkt = torch.empty(nb, device="cuda", dtype=torch.uint8)
+    flag = torch.full((64,), 7, device="cuda", dtype=torch.int32)
+    _lib.check(lib.dp_adj_pack(ad.data_ptr(), pk.data_ptr(), pkt.data_ptr(), flag.data_ptr(), B, n, S()))
+    wsb = lib.dp_adj_aggregate_packed_workspace_bytes(B, n, C)
+    ws = ws_of(wsb)
+    _lib.check(lib.dp_adj_aggregate_packed(ad.data_ptr(), pk.data_ptr(), pkt.data_ptr(), flag.data_ptr(),
+                                           Vd.data_ptr(), V.shape[2], Ud.data_ptr(), C, B, n, C, trans, beta,
+                                           ws.data_ptr(), wsb, S()))
+    return Ud, int(flag[0])
+
+
+@pytest.mark.parametrize("trans", [0, 1])
+@pytest.mark.parametrize("B,n,C", [(3, 128, 5), (20, 500, 40), (4, 500, 70), (2, 1024, 33), (2, 516, 128),
+                                   (2, 200, 50), (3, 131, 17)])
+def test_packed_aggregate_binary_adjacency_is_fp32_exact(lib, trans, B, n, C):
+    """0/1 adjacency: the bf16 x (hi+mid+lo) path must agree with the fp64 product to fp32 rounding — every
+    product is exact, only the fp32 accumulation order differs."""
+    g = torch.Generator().manual_seed(n * 3 + C)
+    adj = (torch.rand(B, n, n, generator=g) < 0.05).float()          # not symmetric on purpose
+    V = torch.randn(B, n, C + 1, generator=g) * torch.exp(torch.randn(B, n, C + 1, generator=g) * 3)  # wide range
+    U0 = torch.randn(B, n, C, generator=g)
+    Ud, flag = _packed_aggregate(lib, adj, V, C, trans, 0.25, U0)
+    assert flag == 0
+    opA = adj.transpose(1, 2) if trans else adj
+    ref = opA.double() @ V[:, :, :C].double() + 0.25 * U0.double()
+    close(Ud, ref.float(), 2e-6, 1e-5 * float(ref.abs().max()) / 10)
+
+
+def test_packed_aggregate_other_bf16_exact_values(lib):
+    # any bf16-representable weights qualify, not just 0/1
+    B, n, C = 2, 256, 20
+    g = torch.Generator().manual_seed(1)
+    vals = torch.tensor([0.0, 0.5, 1.0, -2.0, 3.0, 0.0078125])
+    adj = vals[torch.randint(0, 6, (B, n, n), generator=g)]
+    V = torch.randn(B, n, C, generator=g)
+    Ud, flag = _packed_aggregate(lib, adj, V, C, 0, 0.0, torch.zeros(B, n, C))
+    assert flag == 0
+    close(Ud, (adj.double() @ V.double()).float(), 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("trans", [0, 1])
+def test_packed_aggregate_falls_back_when_not_bf16_exact(lib, trans):
+    # a single entry with low mantissa bits set flips the device flag: the fp32 loop must run (and be right)
+    B, n, C = 2, 260, 24
+    g = torch.Generator().manual_seed(2)
+    adj = (torch.rand(B, n, n, generator=g) < 0.1).float()
+    adj[1, 200, 37] = 0.3                                     # not representable in bf16
+    V = torch.randn(B, n, C, generator=g)
+    Ud, flag = _packed_aggregate(lib, adj, V, C, trans, 0.0, torch.zeros(B, n, C))
+    assert flag != 0
+    opA = adj.transpose(1, 2) if trans else adj
+    close(Ud, (opA.double() @ V.double()).float(), 1e-4, 1e-4)
+
+
 # ------------------------------------------------------------------ A1 GraphConv
 @pytest.mark.parametrize("add_self,bias,normalize", [(0, 1, 1), (1, 1, 1), (0, 0, 1), (1, 0, 0)])
 @pytest.mark.parametrize("B,n,fin,fout", [(3, 16, 5, 8), (2, 100, 89, 20), (2, 37, 20, 50)])
