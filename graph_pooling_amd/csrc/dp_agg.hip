@@ -40,8 +40,11 @@ struct AggArgs {
     const unsigned short* pk_A;
     int pk_ld;
     const int* pk_flag;
-    const unsigned short* Vs;   // [B][3][CT][K8][16][8]
+    const unsigned short* Vs;   // [B][3][vs_ct][K8][16][8]
     int vs_k8;
+    int vs_ct;                  // ceil(C / 16)
+    int nchunks;                // column chunks of CT*16 (C > 128: the panel stays in LDS, chunks loop inside)
+    int red_off;                // LDS offset (floats) of the cross-wave reduction area
     // plain epilogue
     float* U;            // [B, n, C] (ldu) or null
     int ldu;
@@ -75,7 +78,7 @@ __device__ inline float agg_team_sum(float v) {
 // exact-fp32 accumulate: acc += op(A)[r0.., :] · V   (any adjacency values)
 template <bool TRANS, int CT, int AGG_RT>
 __device__ __forceinline__ void accumulate_fp32(const AggArgs& a, int b, int r0, float* lds,
-                                                f32x4 (&acc)[AGG_RT / 16][CT]) {
+                                                f32x4 (&acc)[AGG_RT / 16][CT], int chunk) {
     constexpr int MI = AGG_RT / 16;
     const int n = a.n;
     const float* A = a.A + (long)b * n * n;
@@ -105,7 +108,7 @@ __device__ __forceinline__ void accumulate_fp32(const AggArgs& a, int b, int r0,
             for (int j = 0; j < 4; ++j) {
                 const float* vrow = V + (long)min(k0 + j, n - 1) * a.ldv;
 #pragma unroll
-                for (int cb = 0; cb < CT; ++cb) dst[j][cb] = vrow[min(cb * 16 + l15, a.C - 1)];
+                for (int cb = 0; cb < CT; ++cb) dst[j][cb] = vrow[min((chunk * CT + cb) * 16 + l15, a.C - 1)];
             }
         };
         auto mma = [&](int step, const float (&bf)[4][CT]) {
@@ -199,13 +202,14 @@ __device__ inline void dma16_raw(const void* src, void* lds_dst) {
 // LDS panel image: [RT][ldp] bf16, ldp = 8 (mod 128)  -> ds_read_b128 A-fragment reads are conflict-free.
 template <int CT, int AGG_RT>
 __device__ __forceinline__ void accumulate_bf16(const AggArgs& a, int b, int r0, float* ldsf,
-                                                f32x4 (&acc)[AGG_RT / 16][CT]) {
+                                                f32x4 (&acc)[AGG_RT / 16][CT], int chunk, bool stage) {
     constexpr int MI = AGG_RT / 16;
     unsigned short* lds = reinterpret_cast<unsigned short*>(ldsf);
     const int n = a.n, np = a.pk_ld;
     const unsigned short* A = a.pk_A + (long)b * n * np;
     const int K8 = a.vs_k8;
-    const unsigned short* Vs = a.Vs + (long)b * 3 * CT * K8 * 128;
+    const int CTt = a.vs_ct;
+    const unsigned short* Vs = a.Vs + (long)b * 3 * CTt * K8 * 128;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
@@ -221,7 +225,7 @@ __device__ __forceinline__ void accumulate_bf16(const AggArgs& a, int b, int r0,
 #pragma unroll
             for (int cb = 0; cb < CT; ++cb)
                 dst[p][cb] = *reinterpret_cast<const agg_s16x8*>(
-                    Vs + ((((long)p * CT + cb) * K8 + st * 4 + kq) * 16 + l15) * 8);
+                    Vs + ((((long)p * CTt + min(chunk * CT + cb, CTt - 1)) * K8 + st * 4 + kq) * 16 + l15) * 8);
     };
     auto mma = [&](int step, const agg_s16x8 (&bf)[3][CT]) {
         agg_s16x8 av[MI];
@@ -241,14 +245,16 @@ __device__ __forceinline__ void accumulate_bf16(const AggArgs& a, int b, int r0,
     load_b(wave, f0);
     load_b(wave + 4, f1);
     // rows r0..r0+RT-1 of the packed operand: pieces (row i, segment s) of 512 bf16 = 1 KiB
-    const int pieces = AGG_RT * segs;
-    for (int pc = wave; pc < pieces; pc += 4) {
-        const int i = pc / segs, s = pc % segs;
-        const int row = min(r0 + i, n - 1);
-        const int col = min(s * 512 + lane * 8, np - 8);   // clamp: finite duplicates, they meet zero V planes
-        dma16_raw(A + (long)row * np + col, lds + i * ldp + s * 512);
+    if (stage) {
+        const int pieces = AGG_RT * segs;
+        for (int pc = wave; pc < pieces; pc += 4) {
+            const int i = pc / segs, s = pc % segs;
+            const int row = min(r0 + i, n - 1);
+            const int col = min(s * 512 + lane * 8, np - 8);   // clamp: finite duplicates, they meet zero V planes
+            dma16_raw(A + (long)row * np + col, lds + i * ldp + s * 512);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int step = wave; step < steps; step += 8) {
         mma(step, f0);
         if (step + 4 < steps) {
@@ -260,7 +266,8 @@ __device__ __forceinline__ void accumulate_bf16(const AggArgs& a, int b, int r0,
     __syncthreads();
 }
 
-template <bool TRANS, int CT, int AGG_RT>
+// MULTI: C > 128 — column chunks of CT*16 loop inside the kernel with the panel kept in LDS
+template <bool TRANS, int CT, int AGG_RT, bool MULTI>
 __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     constexpr int MI = AGG_RT / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -282,52 +289,56 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
 
-    f32x4 acc[MI][CT];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < CT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     const bool use_bf16 = a.pk_A != nullptr && __builtin_amdgcn_readfirstlane(*a.pk_flag) == 0;
-    if (use_bf16)
-        accumulate_bf16<CT, AGG_RT>(a, b, r0, lds, acc);
-    else
-        accumulate_fp32<TRANS, CT, AGG_RT>(a, b, r0, lds, acc);
-
-    // ---------------- cross-wave reduction through LDS: red[wave][32][CTP]
     constexpr int CTP = CT * 16 + 1;
-    float* red = lds;
+    const int nchunks = MULTI ? a.nchunks : 1;
+    float* red = lds + (MULTI ? a.red_off : 0);        // [wave][RT][CTP]; overlays the panel when there is 1 chunk
+    float* tile = red + 4 * AGG_RT * CTP;              // summed tile [RT][CTP]
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        f32x4 acc[MI][CT];
 #pragma unroll
-    for (int rb = 0; rb < MI; ++rb)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int cb = 0; cb < CT; ++cb)
+            for (int j = 0; j < CT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (use_bf16)
+            accumulate_bf16<CT, AGG_RT>(a, b, r0, lds, acc, chunk, chunk == 0);
+        else
+            accumulate_fp32<TRANS, CT, AGG_RT>(a, b, r0, lds, acc, chunk);
+
+        // ---------------- cross-wave reduction through LDS
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                red[(wave * AGG_RT + rb * 16 + kq * 4 + r) * CTP + cb * 16 + l15] = acc[rb][cb][r];
-    __syncthreads();
-    float* tile = lds + 4 * AGG_RT * CTP;              // summed tile [32][CTP]
-    for (int e = threadIdx.x; e < AGG_RT * CT * 16; e += 256) {
-        const int r = e / (CT * 16), c = e % (CT * 16);
-        const float s = red[(0 * AGG_RT + r) * CTP + c] + red[(1 * AGG_RT + r) * CTP + c] +
-                        red[(2 * AGG_RT + r) * CTP + c] + red[(3 * AGG_RT + r) * CTP + c];
-        if (a.U) {
-            const int row = r0 + r;
-            if (row < n && c < a.C) {
-                float* u = a.U + ((long)b * n + row) * a.ldu + c;
-                *u = (a.beta != 0.f) ? s + a.beta * (*u) : s;
+        for (int rb = 0; rb < MI; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < CT; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[(wave * AGG_RT + rb * 16 + kq * 4 + r) * CTP + cb * 16 + l15] = acc[rb][cb][r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < AGG_RT * CT * 16; e += 256) {
+            const int r = e / (CT * 16), c = e % (CT * 16);
+            const int cg = chunk * CT * 16 + c;            // column in the full operand
+            const float s = red[(0 * AGG_RT + r) * CTP + c] + red[(1 * AGG_RT + r) * CTP + c] +
+                            red[(2 * AGG_RT + r) * CTP + c] + red[(3 * AGG_RT + r) * CTP + c];
+            if (a.U) {
+                const int row = r0 + r;
+                if (row < n && cg < a.C) {
+                    float* u = a.U + ((long)b * n + row) * a.ldu + cg;
+                    *u = (a.beta != 0.f) ? s + a.beta * (*u) : s;
+                }
+            } else {
+                // fold bias (+ the add_self operand) in here, with ONE round of coalesced global loads, so the
+                // row passes below read LDS only
+                float u = s;
+                if (c < a.C) {
+                    const int g = (a.g.G == 2 && c >= a.g.c0[1]) ? 1 : 0;
+                    const float* bias = a.bias.p[g];
+                    if (bias) u += bias[c - a.g.c0[g]];
+                    if (a.P && r0 + r < n) u += a.P[((long)b * n + r0 + r) * a.ldv + c];
+                }
+                tile[r * CTP + c] = u;
             }
-        } else {
-            // fold bias (+ the add_self operand) in here, with ONE round of coalesced global loads, so the
-            // row passes below read LDS only
-            float u = s;
-            if (c < a.C) {
-                const int g = (a.g.G == 2 && c >= a.g.c0[1]) ? 1 : 0;
-                const float* bias = a.bias.p[g];
-                if (bias) u += bias[c - a.g.c0[g]];
-                if (a.P && r0 + r < n) u += a.P[((long)b * n + r0 + r) * a.ldv + c];
-            }
-            tile[r * CTP + c] = u;
         }
+        if (MULTI) __syncthreads();                        // red is rewritten by the next chunk
     }
     if (a.U) return;
     __syncthreads();
@@ -372,58 +383,77 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     }
 }
 
-static size_t agg_lds_bytes(bool trans, int n, int CT, int RT) {
+static int agg_ct(int C) { return C <= 128 ? (C + 15) / 16 : 8; }
+static int agg_chunks(int C) { return C <= 128 ? 1 : (C + 127) / 128; }
+static size_t agg_panel_floats(bool trans, int n, int RT) {
     const int kpanel = trans ? n : (n < AGG_KP ? n : AGG_KP);
     const int segs = (kpanel + 255) / 256;
     const size_t panel = trans ? (size_t)((n + 15) / 16) * 16 * RT : (size_t)RT * (segs * 256 + 4);
-    const size_t red = (size_t)5 * RT * (CT * 16 + 1);
     const size_t pk = ((size_t)RT * (((n + 511) / 512) * 512 + 8) * 2 + 3) / 4;     // bf16 panel, in floats
-    size_t m = panel > red ? panel : red;
-    if (pk > m) m = pk;
-    return m * sizeof(float);
+    return ((panel > pk ? panel : pk) + 3) & ~size_t(3);
+}
+static size_t agg_lds_bytes(bool trans, int n, int CT, int RT, int nchunks) {
+    const size_t panel = agg_panel_floats(trans, n, RT);
+    const size_t red = (size_t)5 * RT * (CT * 16 + 1);
+    // one chunk: the reduction area overlays the panel; several: it sits behind it (the panel must survive)
+    return (nchunks > 1 ? panel + red : (panel > red ? panel : red)) * sizeof(float);
 }
 // 16-row tiles when 32-row tiles would leave the chip with < 2 workgroups per CU (small batches): twice the
 // workgroups, four co-resident per CU, so one workgroup's panel burst overlaps its neighbours' multiplies.
-static int agg_row_tile(int B, int n) { return ((long)((n + 31) / 32) * B >= 512) ? 32 : 16; }
-
-bool aggregate_supported(const float* A, int n, int C, bool trans) {
-    if (n < 4 || n % 4 != 0 || C < 1 || C > 128) return false;
-    if ((reinterpret_cast<uintptr_t>(A) & 15) != 0) return false;
-    return agg_lds_bytes(trans, n, (C + 15) / 16, 32) <= 160 * 1024;
+static int agg_row_tile(int B, int n, int C, bool trans) {
+    if (agg_lds_bytes(trans, n, agg_ct(C), 32, agg_chunks(C)) > 160 * 1024) return 16;   // 32 rows do not fit
+    return ((long)((n + 31) / 32) * B >= 512) ? 32 : 16;
 }
 
-template <bool TRANS, int CT, int RT>
+bool aggregate_supported(const float* A, int n, int C, bool trans) {
+    // C > 128 stays on the tiled GEMM: a 16/32-row panel re-reads the whole V operand per row tile, which for
+    // wide V (ER: K = 256 clusters) is 25 GB of L2 traffic per pass — measured slower than the fp32 GEMM.  (The
+    // kernel's column-chunk loop handles such shapes correctly; it is kept for a future wide-tile variant.)
+    if (n < 4 || n % 4 != 0 || C < 1 || C > 128) return false;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) != 0) return false;
+    return agg_lds_bytes(trans, n, agg_ct(C), 16, agg_chunks(C)) <= 160 * 1024;
+}
+
+template <bool TRANS, int CT, int RT, bool MULTI>
 static void launch_agg_rt(Seq& q, const AggArgs& a, int B) {
-    const size_t lds = agg_lds_bytes(TRANS, a.n, CT, RT);
+    const int nchunks = agg_chunks(a.C);
+    const size_t lds = agg_lds_bytes(TRANS, a.n, CT, RT, nchunks);
     static bool attr_done = false;   // per instantiation: allow > 64 KiB of dynamic LDS
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate<TRANS, CT, RT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate<TRANS, CT, RT, MULTI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     AggArgs aa = a;
     aa.tiles = (a.n + RT - 1) / RT;
+    aa.nchunks = nchunks;
+    aa.red_off = nchunks > 1 ? (int)agg_panel_floats(TRANS, a.n, RT) : 0;
+    aa.vs_ct = (a.C + 15) / 16;
     static const int dbg = getenv("DP_AGG_DEBUG") ? atoi(getenv("DP_AGG_DEBUG")) : 0;
     aa.dbg = dbg;
-    hipLaunchKernelGGL((k_aggregate<TRANS, CT, RT>), dim3(aa.tiles * B), dim3(256), lds, q.stream, aa);
+    hipLaunchKernelGGL((k_aggregate<TRANS, CT, RT, MULTI>), dim3(aa.tiles * B), dim3(256), lds, q.stream, aa);
 }
-template <bool TRANS, int CT>
+template <bool TRANS, int CT, bool MULTI>
 static void launch_agg(Seq& q, const AggArgs& a, int B) {
-    if (agg_row_tile(B, a.n) == 32) launch_agg_rt<TRANS, CT, 32>(q, a, B);
-    else launch_agg_rt<TRANS, CT, 16>(q, a, B);
+    if (agg_row_tile(B, a.n, a.C, TRANS) == 32) launch_agg_rt<TRANS, CT, 32, MULTI>(q, a, B);
+    else launch_agg_rt<TRANS, CT, 16, MULTI>(q, a, B);
 }
 
 template <bool TRANS>
 static void dispatch_ct(Seq& q, const AggArgs& a, int B) {
-    switch ((a.C + 15) / 16) {
-        case 1: launch_agg<TRANS, 1>(q, a, B); break;
-        case 2: launch_agg<TRANS, 2>(q, a, B); break;
-        case 3: launch_agg<TRANS, 3>(q, a, B); break;
-        case 4: launch_agg<TRANS, 4>(q, a, B); break;
-        case 5: launch_agg<TRANS, 5>(q, a, B); break;
-        case 6: launch_agg<TRANS, 6>(q, a, B); break;
-        case 7: launch_agg<TRANS, 7>(q, a, B); break;
-        default: launch_agg<TRANS, 8>(q, a, B); break;
+    if (agg_chunks(a.C) > 1) {
+        launch_agg<TRANS, 8, true>(q, a, B);
+        return;
+    }
+    switch (agg_ct(a.C)) {
+        case 1: launch_agg<TRANS, 1, false>(q, a, B); break;
+        case 2: launch_agg<TRANS, 2, false>(q, a, B); break;
+        case 3: launch_agg<TRANS, 3, false>(q, a, B); break;
+        case 4: launch_agg<TRANS, 4, false>(q, a, B); break;
+        case 5: launch_agg<TRANS, 5, false>(q, a, B); break;
+        case 6: launch_agg<TRANS, 6, false>(q, a, B); break;
+        case 7: launch_agg<TRANS, 7, false>(q, a, B); break;
+        default: launch_agg<TRANS, 8, false>(q, a, B); break;
     }
 }
 
@@ -467,9 +497,9 @@ void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int
 }
 int adj_pack_ld(int n) { return (n + 7) & ~7; }
 bool adj_pack_supported(int n, int C) {
-    // worth it only for big levels; the packed rows must be 16-byte multiples
+    // worth it only for big levels; the bf16 panel of a 32-row tile must fit LDS beside the reduction area
     return n >= 128 && C >= 1 && C <= 128 &&
-           ((size_t)32 * (((n + 511) / 512) * 512 + 8) * 2 <= 150 * 1024);
+           ((size_t)16 * (((n + 511) / 512) * 512 + 8) * 2 + 5 * 16 * 129 * 4 <= 156 * 1024);
 }
 
 // k_split3: V [B, n, C] fp32 -> three bf16 planes hi, mid, lo with hi + mid + lo == V exactly, in the layout
@@ -550,7 +580,7 @@ bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, cons
                            RowGroups g, GroupPtrs yout, float* invn, float* part, int B, int n, int normalize,
                            int stats_mode, const PackedAdj* pk, unsigned short* vs) {
     const int C = g.c0[g.G - 1] + g.w[g.G - 1];
-    if (!aggregate_supported(A, n, C, false)) return false;
+    if (!aggregate_supported(A, n, C, false) || agg_chunks(C) > 1) return false;   // the tail needs whole rows
     if (!q.ok()) return true;
     AggArgs a{};
     a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = nullptr;

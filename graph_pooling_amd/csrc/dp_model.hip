@@ -295,8 +295,8 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
         // aggregation + GraphConv tail in one launch when the panel kernel takes the shape
         if (!aggregate_rownorm_fwd(q, io.adj, Pj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn,
                                    stats_mode ? part : nullptr, B, n, 1, stats_mode, pk, vs)) {
-            bgemm(q, io.adj, Pj, Uj, nullptr, B, n, ct, n, n, ct, ct, (long)n * n, (long)n * ct, (long)n * ct, false,
-                  false, 1.f, 0.f, 0);
+            // wide / odd shapes: plain aggregation (panel kernel with column chunks, or the generic GEMM) + row pass
+            aggregate(q, io.adj, Pj, ct, Uj, ct, B, n, ct, false, 0.f, pk, vs);
             rownorm_fwd(q, Uj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn,
                         stats_mode ? part : nullptr, (long)B * n, 1, stats_mode);
         }

@@ -76,7 +76,7 @@ def test_bgemm_asymmetric_identity_and_strides(lib):
 # ------------------------------------------------------------------ adjacency aggregation (panel kernel)
 @pytest.mark.parametrize("trans", [0, 1])
 @pytest.mark.parametrize("B,n,C", [(3, 16, 5), (2, 100, 40), (20, 500, 70), (2, 500, 128), (1, 1024, 33),
-                                   (2, 1100, 20), (2, 67, 9), (2, 260, 130)])
+                                   (2, 1100, 20), (2, 67, 9), (2, 260, 130), (2, 512, 276), (1, 1024, 256)])
 def test_adj_aggregate(lib, trans, B, n, C):
     g = torch.Generator().manual_seed(n + C)
     adj = (torch.rand(B, n, n, generator=g) < 0.1).float() * torch.rand(B, n, n, generator=g)
@@ -121,7 +121,7 @@ def _packed_aggregate(lib, adj, V, C, trans, beta, U0):
 
 @pytest.mark.parametrize("trans", [0, 1])
 @pytest.mark.parametrize("B,n,C", [(3, 128, 5), (20, 500, 40), (4, 500, 70), (2, 1024, 33), (2, 516, 128),
-                                   (2, 200, 50), (3, 131, 17)])
+                                   (2, 200, 50), (3, 131, 17), (2, 512, 276), (1, 1024, 256), (2, 260, 130)])
 def test_packed_aggregate_binary_adjacency_is_fp32_exact(lib, trans, B, n, C):
     """0/1 adjacency: the bf16 x (hi+mid+lo) path must agree with the fp64 product to fp32 rounding — every
     product is exact, only the fp32 accumulation order differs."""
