@@ -98,9 +98,14 @@ def cpu_baseline(cpu, w, linkpred, budget_s=15.0):
 
 def roofline_probe(w, device, iters=200):
     """Average duration of the dominant kernel, HIP events on the launch stream: the level-0 adjacency
-    aggregation  U[b] = A[b] (N x N) · V[b] (N x C),  C = H_embed + H_assign, through the same entry the
-    encoder plan uses (dp_adj_aggregate -> k_aggregate<false, ceil(C/16)>).
-    Algorithmic bytes per launch = B*N*N*4 (A, fp32 as the caller delivers it) + 2*B*N*C*4 (V read, U written)."""
+    aggregation  U[b] = A[b] (N x N) · V[b] (N x C),  C = H_embed + H_assign, exactly as the encoder plan runs it
+    for 0/1 adjacency: k_aggregate on the bf16-packed adjacency (dp_adj_pack) with V's three bf16 planes already
+    written by V's producer (presplit) — so only the aggregation kernel is inside the timed region.
+
+    Bytes per launch are the ALGORITHMIC bytes at the element sizes the kernel really reads:
+      A as bf16: B*N*ld*2;  V as 3 bf16 planes (k padded to 32, C to 16): B*3*ceil(C/16)*ceil(N/32)*4*256;
+      U written as fp32: B*N*C*4.
+    `fp32_equiv` re-expresses the same launch against the reference's fp32 operands (B*N*N*4 + 2*B*N*C*4)."""
     from graph_pooling_amd import _lib
     lib = _lib.load()
     B, N, Cc = w["B"], w["N"], 2 * w["H"]
@@ -108,25 +113,48 @@ def roofline_probe(w, device, iters=200):
     V = torch.randn(B, N, Cc, device=device)
     U = torch.empty(B, N, Cc, device=device)
     st = torch.cuda.current_stream()
+    nb = lib.dp_adj_pack_bytes(B, N)
+    pk = torch.empty(nb, device=device, dtype=torch.uint8)
+    pkt = torch.empty(nb, device=device, dtype=torch.uint8)
+    flag = torch.zeros(64, device=device, dtype=torch.int32)
+    _lib.check(lib.dp_adj_pack(A.data_ptr(), pk.data_ptr(), pkt.data_ptr(), flag.data_ptr(), B, N, st.cuda_stream))
+    wsb = lib.dp_adj_aggregate_packed_workspace_bytes(B, N, Cc)
+    ws = torch.empty(wsb, device=device, dtype=torch.uint8)
 
-    def launch():
-        _lib.check(lib.dp_adj_aggregate(A.data_ptr(), V.data_ptr(), Cc, U.data_ptr(), Cc, B, N, Cc, 0, 0.0,
-                                        st.cuda_stream))
+    def launch(presplit):
+        _lib.check(lib.dp_adj_aggregate_packed(A.data_ptr(), pk.data_ptr(), pkt.data_ptr(), flag.data_ptr(),
+                                               V.data_ptr(), Cc, U.data_ptr(), Cc, B, N, Cc, 0, 0.0, presplit,
+                                               ws.data_ptr(), wsb, st.cuda_stream))
+    launch(0)                      # writes the split into the workspace
+    packed = N >= 128              # below that the plan (and this call) run the fp32 panel kernel
     for _ in range(20):
-        launch()
+        launch(1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
     for _ in range(iters):
-        launch()
+        launch(1)
     e1.record(st)
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1000.0 / iters
-    bytes_alg = B * N * N * 4 + 2 * B * N * Cc * 4
+    ld = lib.dp_adj_pack_ld(N)
+    ct, k8 = (Cc + 15) // 16, ((N + 31) // 32) * 4
+    fp32_bytes = B * N * N * 4 + 2 * B * N * Cc * 4
+    bytes_alg = (B * N * ld * 2 + B * 3 * ct * k8 * 256 + B * N * Cc * 4) if packed else fp32_bytes
     achieved = bytes_alg / (us * 1e-6) / 1e9
+    traffic = None
+    try:                           # PMC traffic of this kernel at this shape, measured with rocprofv3 (profiles/)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        key = f"B{B}_N{N}_C{Cc}"
+        traffic = t.get("k_aggregate_packed" if packed else "k_aggregate_fp32", {}).get(key)
+    except Exception:              # noqa: BLE001
+        traffic = None
     return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                kernel=f"k_aggregate<false,{(Cc + 15) // 16}> (level-0 adjacency aggregation A·[XW_e|XW_a])",
-                us_per_launch=round(us, 2), algorithmic_bytes=bytes_alg)
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                kernel=f"k_aggregate<false,{ct},16> " + ("bf16-packed A x 3-plane bf16 V (exact)" if packed
+                                                          else "fp32 panel") + " — level-0 aggregation A·[XW_e|XW_a]",
+                us_per_launch=round(us, 2), algorithmic_bytes=bytes_alg,
+                fp32_equiv={"bytes": fp32_bytes, "GB/s": round(fp32_bytes / (us * 1e-6) / 1e9, 1)})
 
 
 def main():

@@ -63,7 +63,7 @@ _PROTOS = {
     "dp_adj_pack_bytes": (_Z, [_I, _I]),
     "dp_adj_pack": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "dp_adj_aggregate_packed_workspace_bytes": (_Z, [_I, _I, _I]),
-    "dp_adj_aggregate_packed": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    "dp_adj_aggregate_packed": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
     "dp_gcn_layer_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "dp_gcn_layer_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "dp_gcn_layer_bwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),

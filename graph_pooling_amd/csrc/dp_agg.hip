@@ -545,6 +545,12 @@ static void split3(Seq& q, const float* V, int ldv, unsigned short* Vs, int B, i
     q.check_launch("split3");
 }
 
+// true when aggregate()/aggregate_rownorm_fwd() will take the packed path for this shape (so a producer may
+// emit the split operand itself)
+bool aggregate_packed_usable(const float* A, int n, int C) {
+    return aggregate_supported(A, n, C, false) && adj_pack_supported(n, C);
+}
+
 static void fill_packed(AggArgs& a, const PackedAdj* pk, bool trans, const unsigned short* vs, int n) {
     a.pk_A = trans ? pk->At : pk->A;
     a.pk_ld = pk->ld;
@@ -557,7 +563,7 @@ static void fill_packed(AggArgs& a, const PackedAdj* pk, bool trans, const unsig
 // does not take (n not a multiple of 4, C > 128, unaligned A).  With `pk` (a packed copy of A from adj_pack) and a
 // scratch buffer `vs` (split3_elems) the bf16 path is taken when the device flag says A is bf16-exact.
 void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ldu, int B, int n, int C, bool trans,
-               float beta, const PackedAdj* pk, unsigned short* vs) {
+               float beta, const PackedAdj* pk, unsigned short* vs, bool vs_ready) {
     if (!q.ok()) return;
     if (!aggregate_supported(A, n, C, trans)) {
         bgemm(q, A, V, U, nullptr, B, n, C, n, n, ldv, ldu, (long)n * n, (long)n * ldv, (long)n * ldu, trans, false,
@@ -567,7 +573,7 @@ void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ld
     AggArgs a{};
     a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = U; a.ldu = ldu; a.beta = beta;
     if (pk && vs && adj_pack_supported(n, C)) {
-        split3(q, V, ldv, vs, B, n, C);
+        if (!vs_ready) split3(q, V, ldv, vs, B, n, C);
         fill_packed(a, pk, trans, vs, n);
     }
     if (trans) dispatch_ct<true>(q, a, B); else dispatch_ct<false>(q, a, B);
@@ -578,7 +584,7 @@ void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ld
 // apply_bn partial statistics.  Returns false (nothing launched) when the shape needs the generic path.
 bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, const float* P, GroupCPtrs bias,
                            RowGroups g, GroupPtrs yout, float* invn, float* part, int B, int n, int normalize,
-                           int stats_mode, const PackedAdj* pk, unsigned short* vs) {
+                           int stats_mode, const PackedAdj* pk, unsigned short* vs, bool vs_ready) {
     const int C = g.c0[g.G - 1] + g.w[g.G - 1];
     if (!aggregate_supported(A, n, C, false) || agg_chunks(C) > 1) return false;   // the tail needs whole rows
     if (!q.ok()) return true;
@@ -587,7 +593,7 @@ bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, cons
     a.P = P; a.bias = bias; a.g = g; a.yout = yout; a.invn = invn; a.part = part;
     a.normalize = normalize; a.stats_mode = stats_mode;
     if (pk && vs && adj_pack_supported(n, C)) {
-        split3(q, V, ldv, vs, B, n, C);
+        if (!vs_ready) split3(q, V, ldv, vs, B, n, C);
         fill_packed(a, pk, false, vs, n);
     }
     dispatch_ct<false>(q, a, B);

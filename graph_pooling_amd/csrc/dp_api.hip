@@ -259,7 +259,7 @@ size_t dp_adj_aggregate_packed_workspace_bytes(int B, int n, int C) {
 }
 int dp_adj_aggregate_packed(const float* adj, const void* packed, const void* packed_t, const int* flag,
                             const float* V, int ldv, float* U, int ldu, int B, int n, int C, int trans, float beta,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+                            int presplit, void* workspace, size_t workspace_bytes, void* stream) {
     NOTNULL(adj); NOTNULL(packed); NOTNULL(packed_t); NOTNULL(flag); NOTNULL(V); NOTNULL(U);
     NONNEG(B); NONNEG(n); NONNEG(C);
     DP_CHECK_ARG(ldv >= C && ldu >= C, "ldv=%d/ldu=%d smaller than C=%d", ldv, ldu, C);
@@ -267,7 +267,7 @@ int dp_adj_aggregate_packed(const float* adj, const void* packed, const void* pa
     unsigned short* vs = q.alloc<unsigned short>(split3_elems(B, n, C));
     if (q.err) return q.err;
     PackedAdj pk{(const unsigned short*)packed, (const unsigned short*)packed_t, adj_pack_ld(n), flag};
-    aggregate(q, adj, V, ldv, U, ldu, B, n, C, trans != 0, beta, &pk, vs);
+    aggregate(q, adj, V, ldv, U, ldu, B, n, C, trans != 0, beta, &pk, vs, presplit != 0);
     return q.err;
 }
 

@@ -103,7 +103,32 @@ struct GemmDesc {
     int act;
     long sK;       // split-K: partial of K range ks goes to C + ks*sK (0: all ranges share C)
     int atomic;    // split-K ranges add into C with float atomics
+    // optional second output: the exact 3-plane bf16 split of C in the layout the bf16 aggregation wants
+    // (Vs[b][plane][cb][k8][c][j], see dp_agg.hip) — lets the producer of an aggregation operand emit it
+    // directly instead of a separate split pass.  Rows M..8*split_k8-1 are written as zeros.
+    unsigned short* split_out;
+    int split_ct, split_k8, split_c0;   // total column blocks, k8 groups, column offset of this problem in V
 };
+
+// hi/mid/lo bf16 planes with hi + mid + lo == v exactly (round-to-nearest-even at each step)
+__device__ inline void bf16_split3(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+    auto rn = [](float x) -> unsigned {
+        unsigned u = __float_as_uint(x);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return u >> 16;
+    };
+    const unsigned hh = rn(v);
+    const float r1 = v - __uint_as_float(hh << 16);
+    const unsigned mm = rn(r1);
+    const float r2 = r1 - __uint_as_float(mm << 16);
+    h = (unsigned short)hh;
+    m = (unsigned short)mm;
+    l = (unsigned short)rn(r2);
+}
+// element offset of Vs[plane][cb][k8][c][j] inside one graph's block
+__device__ __host__ inline long vs_index(int plane, int CTt, int K8, int cb, int k8, int c, int j) {
+    return ((((long)plane * CTt + cb) * K8 + k8) * 16 + c) * 8 + j;
+}
 // ksplit > 1 cuts K into ranges run by different workgroups (contractions over the node index have K = n
 // = 500 but outputs of a few KB: without it they are 40-80 workgroups walking 16 dependent k-steps).
 void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit = 1);
@@ -136,7 +161,7 @@ void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat /*BN output, null when n
                  const float* invn, const float* stats, const float* part2, RowGroups g, float* dU, int ldu,
                  const GroupPtrs* dbias /*per group: bias-gradient slab of graph 0 (ld = distance between graphs);
                  column sums of dU are atomically added; null: none*/, int B, int n, int has_relu, int has_bn,
-                 int normalize);
+                 int normalize, unsigned short* vs = nullptr /*also emit the 3-plane bf16 split of dU*/);
 int rownorm_bwd_chunks(int n);
 void colsum_batched(Seq& q, const float* X, int ldx, long strideX, int rows, int cols, float* out,
                     long strideOut, int batch, int rowsplit = 1);
@@ -166,11 +191,14 @@ void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int
 int adj_pack_ld(int n);
 bool adj_pack_supported(int n, int C);
 size_t split3_elems(int B, int n, int C);
+// vs_ready: the producer of V already wrote its 3-plane split into `vs` (no split pass needed)
 void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ldu, int B, int n, int C, bool trans,
-               float beta, const PackedAdj* pk = nullptr, unsigned short* vs = nullptr);
+               float beta, const PackedAdj* pk = nullptr, unsigned short* vs = nullptr, bool vs_ready = false);
 bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, const float* P, GroupCPtrs bias,
                            RowGroups g, GroupPtrs yout, float* invn, float* part, int B, int n, int normalize,
-                           int stats_mode, const PackedAdj* pk = nullptr, unsigned short* vs = nullptr);
+                           int stats_mode, const PackedAdj* pk = nullptr, unsigned short* vs = nullptr,
+                           bool vs_ready = false);
+bool aggregate_packed_usable(const float* A, int n, int C);
 
 // (dp_small.hip) one-workgroup-per-graph GCN layers of a pooled level (n <= 64)
 bool small_level_supported(int B, int n, int din, int dout);

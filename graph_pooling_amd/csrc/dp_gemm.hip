@@ -42,6 +42,8 @@ struct GemmArgs {
     int ksplit;       // K is cut into `ksplit` ranges handled by different workgroups (blockIdx.y = b*ksplit + ks)
     long sK;          // != 0: range ks stores its partial at C + ks*sK (slab rows, summed by the caller's reduce)
     int atomic;       // 1: ranges add into C with float atomics (C pre-zeroed / accumulated into; no bias/act)
+    unsigned short* split_out;            // optional 3-plane bf16 copy of C (see GemmDesc)
+    int split_ct, split_k8, split_c0;
 };
 
 constexpr int KT = 32;
@@ -223,6 +225,26 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
         for (int j = 0; j < NI; ++j) {
             const int col = n0 + wc * WN + j * 16 + l15;
             if (col >= a.N) continue;
+            if (a.split_out) {
+                // this lane holds 4 consecutive rows of one column: half of a k8 group -> one 8-byte store per plane
+                const int row0 = m0 + wr * WM + i * 16 + l4 * 4;
+                if (row0 < a.split_k8 * 8) {
+                    const int vc = a.split_c0 + col;
+                    unsigned short* vb = a.split_out + (long)b * 3 * a.split_ct * a.split_k8 * 128;
+                    unsigned short h[4], m[4], l[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = (row0 + r < a.M) ? a.alpha * acc[i][j][r] + (a.bias ? a.bias[col] : 0.f) : 0.f;
+                        bf16_split3(v, h[r], m[r], l[r]);
+                    }
+                    const long o = vs_index(0, a.split_ct, a.split_k8, vc >> 4, row0 >> 3, vc & 15, row0 & 7);
+                    const long pl = (long)a.split_ct * a.split_k8 * 128;
+                    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<u16x4*>(vb + o) = (u16x4){h[0], h[1], h[2], h[3]};
+                    *reinterpret_cast<u16x4*>(vb + o + pl) = (u16x4){m[0], m[1], m[2], m[3]};
+                    *reinterpret_cast<u16x4*>(vb + o + 2 * pl) = (u16x4){l[0], l[1], l[2], l[3]};
+                }
+            }
             const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -279,7 +301,9 @@ static void launch_tile(Seq& q, GemmGroupArgs& g, int batch) {
         GemmArgs& a = g.p[i];
         a.tilesN = (a.N + BN - 1) / BN;
         g.tile0[i] = total;
-        total += ((a.M + BM - 1) / BM) * a.tilesN;
+        // with a split output the zero rows M..8*k8-1 of the operand must be written too
+        const int mrows = a.split_out && a.split_k8 * 8 > a.M ? a.split_k8 * 8 : a.M;
+        total += ((mrows + BM - 1) / BM) * a.tilesN;
     }
     g.tile0[g.count] = total;
     hipLaunchKernelGGL((bgemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(total, batch * g.p[0].ksplit), dim3(256), 0,
@@ -303,7 +327,8 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
         if (s.M <= 0 || s.N <= 0) continue;
         GemmArgs& a = g.p[g.count++];
         a = GemmArgs{s.A, s.B, s.C, s.bias, s.M, s.N, s.K, s.lda, s.ldb, s.ldc, s.sA, s.sB, s.sC, s.alpha, s.beta,
-                     s.act, 0, 0, 0, s.tA ? 1 : 0, s.tB ? 1 : 0, ksplit, s.sK, s.atomic};
+                     s.act, 0, 0, 0, s.tA ? 1 : 0, s.tB ? 1 : 0, ksplit, s.sK, s.atomic,
+                     s.split_out, s.split_ct, s.split_k8, s.split_c0};
         a.vecA = aligned16(s.A) && (s.lda % 4 == 0) && (s.sA % 4 == 0);
         a.vecB = aligned16(s.B) && (s.ldb % 4 == 0) && (s.sB % 4 == 0);
         if (s.N > maxN) maxN = s.N;
@@ -338,7 +363,7 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
 void bgemm(Seq& q, const float* A, const float* B, float* C, const float* bias, int batch, int M, int N,
            int K, int lda, int ldb, int ldc, long sA, long sB, long sC, bool tA, bool tB, float alpha,
            float beta, int act) {
-    GemmDesc d{A, B, C, bias, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, alpha, beta, act, 0, 0};
+    GemmDesc d{A, B, C, bias, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, alpha, beta, act, 0, 0, nullptr, 0, 0, 0};
     bgemm_group(q, &d, 1, batch, 1);
 }
 

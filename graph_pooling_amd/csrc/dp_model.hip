@@ -226,7 +226,7 @@ struct LevelIO {
 
 // P = [x_e W_e | x_a W_a]  for layer l of level li  (one grouped launch)
 void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
-               const float* params, int l, float* Pj) {
+               const float* params, int l, float* Pj, unsigned short* vs_split = nullptr) {
     const int ct = li.ctot[l];
     const int B = c.B, n = li.n;
     GemmDesc d[2];
@@ -244,7 +244,8 @@ void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const Level
         }
         const int c0 = g == 0 ? 0 : li.e->dims[l + 1];
         d[g] = GemmDesc{xin, PW(params, st->w_off[l]), Pj + c0, nullptr, n, dout, din, ldin, dout, ct,
-                        (long)n * ldin, 0, (long)n * ct, false, false, 1.f, 0.f, 0};
+                        (long)n * ldin, 0, (long)n * ct, false, false, 1.f, 0.f, 0, 0, 0,
+                        vs_split, (ct + 15) / 16, ((n + 31) / 32) * 4, c0};
     }
     bgemm_group(q, d, li.G, B);
 }
@@ -274,7 +275,9 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
     for (int l = 0; l < li.L; ++l) {
         const int ct = li.ctot[l];
         const bool last = l == li.L - 1;
-        transform(q, c, li, lv, io, params, l, Pj);
+        // with a packed adjacency the transform GEMM also emits the 3-plane bf16 split the aggregation reads
+        const bool presplit = pk && vs && aggregate_packed_usable(io.adj, n, ct);
+        transform(q, c, li, lv, io, params, l, Pj, presplit ? vs : nullptr);
         RowGroups g = groups_of(li, l);
         GroupCPtrs bias{};
         bias.p[0] = PW(params, li.e->b_off[l]);
@@ -294,9 +297,9 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
         const int stats_mode = (!last && bn) ? 1 : 0;
         // aggregation + GraphConv tail in one launch when the panel kernel takes the shape
         if (!aggregate_rownorm_fwd(q, io.adj, Pj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn,
-                                   stats_mode ? part : nullptr, B, n, 1, stats_mode, pk, vs)) {
+                                   stats_mode ? part : nullptr, B, n, 1, stats_mode, pk, vs, presplit)) {
             // wide / odd shapes: plain aggregation (panel kernel with column chunks, or the generic GEMM) + row pass
-            aggregate(q, io.adj, Pj, ct, Uj, ct, B, n, ct, false, 0.f, pk, vs);
+            aggregate(q, io.adj, Pj, ct, Uj, ct, B, n, ct, false, 0.f, pk, vs, presplit);
             rownorm_fwd(q, Uj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn,
                         stats_mode ? part : nullptr, (long)B * n, 1, stats_mode);
         }
@@ -376,10 +379,11 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
         dbias.p[0] = li.e->b_off[l] >= 0 ? slabs + li.e->b_off[l] : nullptr;
         dbias.p[1] = (li.a && li.a->b_off[l] >= 0) ? slabs + li.a->b_off[l] : nullptr;
         dbias.ld[0] = dbias.ld[1] = (int)gstride;
+        const bool presplit = pk && vs && aggregate_packed_usable(io.adj, n, ct);
         rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, part, g, dUj, ct, &dbias, B, n, !last, has_bn,
-                    1);
+                    1, presplit ? vs : nullptr);
         // G = A^T dU (+ dU)
-        aggregate(q, io.adj, dUj, ct, Gj, ct, B, n, ct, true, 0.f, pk, vs);
+        aggregate(q, io.adj, dUj, ct, Gj, ct, B, n, ct, true, 0.f, pk, vs, presplit);
         if (add_self) axpy(q, Gj, dUj, 1.f, (long)B * n * ct);
         {
             GemmDesc d[4];
@@ -634,17 +638,21 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
         const int n = li.n;
         if (j < P) {
             const int K = li.K, D = li.D;
+            bool vsplit_used = false;
             const float* dXn = gr[j + 1].dX0;
             const float* dAn = gr[j + 1].dAdj;
             {
                 // X' = S^T Z:  dZ += S dX',  dS = Z dX'^T ;  A' = (S^T A) S:  V = S dA'^T,  W = S dA'
+                unsigned short* vsplit =
+                    (j == 0 && pkp && aggregate_packed_usable(io.adj, n, K)) ? vs : nullptr;
+                vsplit_used = vsplit != nullptr;
                 GemmDesc d[4] = {
                     {lv.S, dXn, gr[j].dZe, nullptr, n, D, K, K, D, D, (long)n * K, (long)K * D, (long)n * D, false, false,
                      1.f, 1.f, 0},
                     {lv.Ze, dXn, dS, nullptr, n, K, D, D, D, K, (long)n * D, (long)K * D, (long)n * K, false, true, 1.f,
                      0.f, 0},
                     {lv.S, dAn, V, nullptr, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, true, 1.f, 0.f,
-                     0},
+                     0, 0, 0, vsplit, (K + 15) / 16, ((n + 31) / 32) * 4, 0},
                     {lv.S, dAn, V2, nullptr, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, false, 1.f,
                      0.f, 0}};
                 bgemm_group(q, d, gr[j].dAdj ? 4 : 3, B);
@@ -652,7 +660,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
             // dS += T^T dA' ;  dS += A V
             bgemm(q, lv.T, dAn, dS, nullptr, B, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, false, 1.f,
                   1.f, 0);
-            aggregate(q, io.adj, V, K, dS, K, B, n, K, false, 1.f, j == 0 ? pkp : nullptr, vs);
+            aggregate(q, io.adj, V, K, dS, K, B, n, K, false, 1.f, j == 0 ? pkp : nullptr, vs, vsplit_used);
             if (gr[j].dAdj)   // dA_j += (S dA') S^T
                 bgemm(q, V2, lv.S, gr[j].dAdj, nullptr, B, n, n, K, K, K, n, (long)n * K, (long)n * K, (long)n * n, false,
                       true, 1.f, 1.f, 0);

@@ -223,6 +223,8 @@ struct RownormBwdArgs {
     GroupPtrs dbias;      // per group: this layer's bias-gradient slab (row of graph 0; graphs are dbias.ld apart)
                           // — column sums of dU are ADDED with float atomics (the slabs are zeroed per backward)
     int want_bias;
+    unsigned short* vs;   // optional: exact 3-plane bf16 split of dU for the bf16 aggregation (dp_agg.hip layout)
+    int vs_ct, vs_k8;
     int B, n;
     int rows_per_chunk;
     int has_relu, has_bn, normalize;
@@ -237,8 +239,10 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
     const int ct = a.g.c0[a.g.G - 1] + a.g.w[a.g.G - 1];
     // each 16-lane team owns one row of the LDS accumulator (no atomics: lane c owns columns c, c+16, ...)
     float* mysum = colsum + team * ct;
-    if (a.want_bias) {
-        for (int c = threadIdx.x; c < 16 * ct; c += 256) colsum[c] = 0.f;
+    float* tile8 = colsum + (a.want_bias ? 16 * ct : 0);     // [8 rows][ct] copy of dU for the bf16 split
+    if (a.want_bias || a.vs) {
+        const int tot = (a.want_bias ? 16 * ct : 0) + (a.vs ? 8 * ct : 0);
+        for (int c = threadIdx.x; c < tot; c += 256) colsum[c] = 0.f;
         __syncthreads();
     }
     const int r0 = chunk * a.rows_per_chunk;
@@ -286,10 +290,34 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
             const float v = project ? inv * (d - yy * dot) : inv * d;
             du[c] = v;
             if (a.want_bias) mysum[a.g.c0[g] + c] += v;
+            if (a.vs) tile8[(node - r0) * ct + a.g.c0[g] + c] = v;
         }
     }
+    if (a.want_bias || a.vs) __syncthreads();
+    if (a.vs) {
+        // the 8 rows of this workgroup are exactly one k8 group of the split operand
+        unsigned short* vb = a.vs + (long)b * 3 * a.vs_ct * a.vs_k8 * 128;
+        const long pl = (long)a.vs_ct * a.vs_k8 * 128;
+        typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+        const int last = gridDim.x - 1;
+        const int kend = chunk == last ? a.vs_k8 : chunk + 1;     // the last workgroup also zeroes the padded groups
+        for (int k8 = chunk; k8 < kend; ++k8)
+            for (int vc = threadIdx.x; vc < a.vs_ct * 16; vc += 256) {
+                u16x8 h, m, l;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = (k8 == chunk && vc < ct) ? tile8[j * ct + vc] : 0.f;
+                    unsigned short hh, mm, ll;
+                    bf16_split3(v, hh, mm, ll);
+                    h[j] = hh; m[j] = mm; l[j] = ll;
+                }
+                const long o = vs_index(0, a.vs_ct, a.vs_k8, vc >> 4, k8, vc & 15, 0);
+                *reinterpret_cast<u16x8*>(vb + o) = h;
+                *reinterpret_cast<u16x8*>(vb + o + pl) = m;
+                *reinterpret_cast<u16x8*>(vb + o + 2 * pl) = l;
+            }
+    }
     if (a.want_bias) {
-        __syncthreads();
         for (int c = threadIdx.x; c < ct; c += 256) {
             float t = 0.f;
 #pragma unroll
@@ -303,7 +331,7 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
 int rownorm_bwd_chunks(int n) { return (n + 7) / 8; }
 void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const float* invn, const float* stats,
                  const float* part2, RowGroups g, float* dU, int ldu, const GroupPtrs* dbias, int B, int n,
-                 int has_relu, int has_bn, int normalize) {
+                 int has_relu, int has_bn, int normalize, unsigned short* vs) {
     if (!q.ok()) return;
     GroupPtrs db{};
     int want = 0;
@@ -311,10 +339,11 @@ void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const flo
         db = *dbias;
         want = (db.p[0] || db.p[1]) ? 1 : 0;
     }
-    RownormBwdArgs a{dx, xhat, y, invn, stats, part2, g, dU, ldu, db, want, B, n, 8, has_relu, has_bn, normalize};
     const int ct = g.c0[g.G - 1] + g.w[g.G - 1];
-    hipLaunchKernelGGL(k_rownorm_bwd, dim3(rownorm_bwd_chunks(n), B), dim3(256), want ? 16 * ct * sizeof(float) : 0,
-                       q.stream, a);
+    RownormBwdArgs a{dx, xhat, y, invn, stats, part2, g, dU, ldu, db, want, vs, (ct + 15) / 16, ((n + 31) / 32) * 4,
+                     B, n, 8, has_relu, has_bn, normalize};
+    hipLaunchKernelGGL(k_rownorm_bwd, dim3(rownorm_bwd_chunks(n), B), dim3(256),
+                       ((want ? 16 : 0) + (vs ? 8 : 0)) * ct * sizeof(float), q.stream, a);
     q.check_launch("rownorm_bwd");
 }
 

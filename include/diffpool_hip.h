@@ -76,9 +76,11 @@ int dp_adj_pack_ld(int n);
 size_t dp_adj_pack_bytes(int B, int n);            /* bytes of ONE packed copy */
 int dp_adj_pack(const float* adj, void* packed, void* packed_t, int* flag, int B, int n, void* stream);
 size_t dp_adj_aggregate_packed_workspace_bytes(int B, int n, int C);
+/* presplit != 0: the workspace already holds the 3-plane split of this V from an earlier call (skips the split
+ * pass — the encoder plan gets the split from V's producer kernel the same way). */
 int dp_adj_aggregate_packed(const float* adj, const void* packed, const void* packed_t, const int* flag,
                             const float* V, int ldv, float* U, int ldu, int B, int n, int C, int trans, float beta,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            int presplit, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ A1  GraphConv
  * y = l2norm((adj @ x [+ x]) @ W + b)   — GraphConv.forward, encoders.py:962-974.

@@ -114,8 +114,14 @@ def _packed_aggregate(lib, adj, V, C, trans, beta, U0):
     wsb = lib.dp_adj_aggregate_packed_workspace_bytes(B, n, C)
     ws = ws_of(wsb)
     _lib.check(lib.dp_adj_aggregate_packed(ad.data_ptr(), pk.data_ptr(), pkt.data_ptr(), flag.data_ptr(),
-                                           Vd.data_ptr(), V.shape[2], Ud.data_ptr(), C, B, n, C, trans, beta,
+                                           Vd.data_ptr(), V.shape[2], Ud.data_ptr(), C, B, n, C, trans, beta, 0,
                                            ws.data_ptr(), wsb, S()))
+    if beta == 0.0:      # the split left in the workspace is reusable: a presplit call must give the same bits
+        U2 = torch.empty_like(Ud)
+        _lib.check(lib.dp_adj_aggregate_packed(ad.data_ptr(), pk.data_ptr(), pkt.data_ptr(), flag.data_ptr(),
+                                               Vd.data_ptr(), V.shape[2], U2.data_ptr(), C, B, n, C, trans, beta, 1,
+                                               ws.data_ptr(), wsb, S()))
+        assert torch.equal(U2, Ud)
     return Ud, int(flag[0])
 
 
