@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--linkpred", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe-only", action="store_true",
+                    help="run only the roofline probe (used to profile the dominant kernel in isolation)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,6 +194,9 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} rank(s)", file=sys.stderr)
 
     w = WORKLOADS[args.workload]
+    if args.probe_only:
+        print(json.dumps({"roofline": roofline_probe(w, device)}))
+        return
     model, batch, cpu = make_model_and_batch(w, args.linkpred, device, seed_offset=rank)
     dp = None
     if world > 1:

@@ -179,6 +179,7 @@ void ce_bwd(Seq& q, const float* prob, const long long* label, const float* dlos
             int B, int C);
 void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, long count, int accumulate);
 void axpy(Seq& q, float* y, const float* x, float a, long count);
+void zero_fill(Seq& q, void* p, size_t bytes);   // wide-store zero kernel (falls back to hipMemsetAsync for odd sizes)
 
 // (dp_agg.hip) adjacency-panel aggregation
 struct PackedAdj {               // written by adj_pack: bf16 copies of A and A^T + the exactness flag

@@ -512,7 +512,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
             // X' = S^T Z ;  Tt = A^T S  (= (S^T A)^T, [n x K]) ;  A' = Tt^T S.   X' and A' contract over the node
             // index (K = n): split-K with float atomics into the zeroed outputs when the level is large
             const int ksn = n >= 256 ? node_ksplit(c) : 1;
-            if (ksn > 1) q.zero(lv.Xn, (size_t)((char*)(lv.An + (size_t)B * K * K) - (char*)lv.Xn));
+            if (ksn > 1) zero_fill(q, lv.Xn, align256((size_t)((char*)(lv.An + (size_t)B * K * K) - (char*)lv.Xn)));
             {
                 GemmDesc d{lv.S, lv.Ze, lv.Xn, nullptr, K, li.D, n, K, li.D, li.D, (long)n * K, (long)n * li.D,
                            (long)K * li.D, true, false, 1.f, 0.f, 0, 0, ksn > 1 ? 1 : 0};
@@ -591,9 +591,9 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
 
     // every entry of `grads` is written below (weights: slab reduce / direct GEMM; biases: reduce_bias /
     // column sums), so no memset of it is needed
-    q.zero(q.ws + zero_begin, zero_end - zero_begin);
+    zero_fill(q, q.ws + zero_begin, zero_end - zero_begin);
     // the slabs receive atomic adds (bias sums) and leave split-K rows unused: zero them once per backward
-    q.zero(slabs, (size_t)B * KS * c.n_graph_params * sizeof(float));
+    zero_fill(q, slabs, align256((size_t)B * KS * c.n_graph_params * sizeof(float)));
     // ---- pred_model backward
     for (int i = c.n_pred - 1; i >= 0; --i) {
         const int din = c.pred_dims[i], dout = c.pred_dims[i + 1];

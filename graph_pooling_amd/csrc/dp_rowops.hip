@@ -542,6 +542,27 @@ void mask_rows(Seq& q, const float* src, int lds, float* dst, int ldd, const int
     q.check_launch("mask_rows");
 }
 
+// ------------------------------------------------------------------ zero fill
+// hipMemsetAsync runs its fill kernel on 256 workgroups whatever the size (17 us for the 4 MB of gradient
+// slabs); a plain wide-store kernel is 3-5x faster at these sizes and is just as capturable.
+__global__ __launch_bounds__(256) void k_zero16(uint4* p, long n16) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (long k = i; k < n16; k += stride) p[k] = make_uint4(0, 0, 0, 0);
+}
+void zero_fill(Seq& q, void* p, size_t bytes) {
+    if (!q.ok() || bytes == 0) return;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0 || (bytes & 15) != 0 || bytes < 4096) {
+        q.zero(p, bytes);
+        return;
+    }
+    const long n16 = (long)(bytes / 16);
+    long blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_zero16, dim3((int)blocks), dim3(256), 0, q.stream, (uint4*)p, n16);
+    q.check_launch("zero_fill");
+}
+
 // ------------------------------------------------------------------ small elementwise
 __global__ void k_relu_bwd(float* d, const float* h, long count) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
