@@ -344,7 +344,8 @@ def test_masked_max(lib):
 
 
 # ------------------------------------------------------------------ A8 link loss
-@pytest.mark.parametrize("B,n,K", [(3, 16, 4), (2, 100, 10)])
+@pytest.mark.parametrize("B,n,K", [(3, 16, 4), (2, 100, 10), (3, 200, 20), (2, 150, 40), (2, 132, 50), (2, 130, 90),
+                                   (1, 200, 128), (1, 140, 150), (1, 260, 256)])
 def test_linkpred_loss(lib, B, n, K):
     g = torch.Generator().manual_seed(K)
     _, adj, nn_, _ = O.make_batch(B, n, 3, n_min=1, p=0.2, seed=K)
