@@ -44,6 +44,7 @@ struct AggArgs {
     int vs_k8;
     int vs_ct;                  // ceil(C / 16)
     int nchunks;                // column chunks of CT*16 (C > 128: the panel stays in LDS, chunks loop inside)
+    const int* run_if;          // non-null: the launch is a fallback that runs only when *run_if != 0
     int red_off;                // LDS offset (floats) of the cross-wave reduction area
     // plain epilogue
     float* U;            // [B, n, C] (ldu) or null
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     // L2), so block id -> work id is remapped (bijectively) to give every XCD one CONTIGUOUS run of
     // (graph, row tile) items: the 16 row tiles of a graph then share one L2 for their V operand instead of
     // fetching it into all eight (measured: 32 MB -> ~22 MB of fabric reads per DD launch).
+    if (a.run_if && __builtin_amdgcn_readfirstlane(*a.run_if) == 0) return;
     const int nwg = gridDim.x, tiles = a.tiles;
     int wid;
     {
@@ -380,6 +382,288 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
                 a.part[(row * a.g.G + g) * 2 + 1] = m2;
             }
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Wide-tile variant for big batches and wide operands (ER: B = 256, n = 1024, C up to 320).
+// The 16/32-row panel kernel above re-reads the whole split V operand once per row tile: at n = 1024 that is 32
+// reads of V per graph and the L2 traffic (2.4 GB per pass at C = 40) — not HBM — sets its time; at C = 256 the
+// same product on the fp32 GEMM costs 137 GFLOP of exact-fp32 MFMA.  Here one workgroup owns 128 rows x ALL
+// columns (each wave 32 rows), so V is read n/128 times, and the product runs on the bf16 MFMA against the
+// 3-plane exact split (same arithmetic as accumulate_bf16: bit-identical products, fp32 accumulation).
+//   * A fragments go global -> registers (a wave's rows are its own; nothing to share), four k-steps deep
+//   * the split-V pieces of a k-step (1 KiB each, already in MFMA B-fragment order) are shared by the four
+//     waves: register-staged into a double-buffered LDS image, lane-linear (conflict-free b128 both ways),
+//     one barrier per step.  No LDS-DMA here on purpose: with a glds in flight hipcc drains vmcnt(0) at every
+//     use of an ordinary load (cdna_hip_programming.md §5), which would serialise the A prefetch.
+// Runs only when the pack flag says A is bf16-exact; the caller queues a predicated fp32 launch behind it.
+template <int CT>
+__global__ __launch_bounds__(256) void k_aggregate_wide(AggArgs a) {
+    constexpr int KS = CT <= 8 ? 2 : 1;          // k32 sub-steps per pipeline step
+    constexpr int NP = 3 * CT * KS;              // 1-KiB pieces of split V per step
+    constexpr int PPW = (NP + 3) / 4;            // pieces staged per wave
+    constexpr int NA = CT <= 8 ? 4 : 2;          // A register sets (prefetch distance NA - 1 steps; wide steps are long)
+    constexpr int NB = CT <= 8 ? 3 : 6;          // split-V fragments kept in flight from LDS ahead of their MFMAs
+    extern __shared__ __attribute__((aligned(16))) float ldsf[];
+    if (__builtin_amdgcn_readfirstlane(*a.pk_flag) != 0) return;
+    unsigned short* lds = reinterpret_cast<unsigned short*>(ldsf);
+    const int nwg = gridDim.x, tiles = a.tiles;
+    int wid;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qd = nwg >> 3, rm = nwg & 7;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int b = wid / tiles;
+    const int n = a.n, np = a.pk_ld;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int rw0 = (wid % tiles) * 128 + wave * 32;  // first row of this wave
+    const int steps = (n + 31) / 32;
+    const int psteps = (steps + KS - 1) / KS;
+    const int K8 = a.vs_k8, CTt = a.vs_ct;
+    const unsigned short* Ab = a.pk_A + (long)b * n * np;
+    const unsigned short* Vb = a.Vs + (long)b * 3 * CTt * K8 * 128 + lane * 8;
+    const unsigned short* arow[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) arow[rb] = Ab + (long)min(rw0 + rb * 16 + l15, n - 1) * np;
+
+    agg_s16x8 areg[NA][KS][2];
+    agg_s16x8 vreg[PPW];
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // columns past np - 8 are clamped (finite duplicates; they meet zero rows of the split V).  k-steps past the
+    // end (the rounded-up trip count, the odd half of a two-step stage) read 16 zero bytes instead — the pack
+    // flag block: adj_pack clears 256 bytes of it and this kernel only runs while flag[0] == 0 — so the multiply
+    // loop needs no branch and the loaded registers no select (a select would pull the wait up to the load)
+    const unsigned short* zsrc = reinterpret_cast<const unsigned short*>(a.pk_flag);
+    auto load_a = [&](int ps, agg_s16x8 (&dst)[KS][2]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int s32 = ps * KS + ks;
+            const int col = min(min(s32, steps - 1) * 32 + kq * 8, np - 8);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                dst[ks][rb] = *reinterpret_cast<const agg_s16x8*>(s32 < steps ? arow[rb] + col : zsrc);
+        }
+    };
+    // no predicates around the staging loads/stores (a branch per piece makes hipcc drain vmcnt(0) at each one):
+    // piece ids past NP are clamped to the last piece — a duplicate load and an identical duplicate LDS write
+    auto load_v = [&](int ps) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = min(wave + 4 * i, NP - 1);
+            const int ks = q / (3 * CT), rem = q % (3 * CT), plane = rem / CT, cb = rem % CT;
+            const int s32 = min(ps * KS + ks, steps - 1);
+            vreg[i] = *reinterpret_cast<const agg_s16x8*>(
+                Vb + (((long)plane * CTt + min(cb, CTt - 1)) * K8 + s32 * 4) * 128);
+        }
+    };
+    auto write_v = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = min(wave + 4 * i, NP - 1);
+            *reinterpret_cast<agg_s16x8*>(lds + (buf * NP + q) * 512 + lane * 8) = vreg[i];
+        }
+    };
+    // `buf` is a compile-time constant at every call site, so each fragment read is one base VGPR + an immediate.
+    // Fragment t of a step = (ks, plane, cb) in issue order; NB reads run ahead of the MFMAs that consume them
+    // (sched_group_barrier pins that interleave: hipcc otherwise sinks every read to just before its use).
+    auto compute = [&](int buf, const agg_s16x8 (&af)[KS][2]) {
+        constexpr int T = KS * 3 * CT;
+        constexpr int PRE = NB < T ? NB : T;
+        const unsigned short* base = lds + buf * NP * 512 + lane * 8;
+        auto frag = [&](int t) {
+            const int ks = t / (3 * CT), rem = t % (3 * CT), p = 2 - rem / CT, cb = rem % CT;   // lo, mid, hi
+            return *reinterpret_cast<const agg_s16x8*>(base + ((ks * 3 + p) * CT + cb) * 512);
+        };
+        agg_s16x8 ring[NB];
+#pragma unroll
+        for (int t = 0; t < PRE; ++t) ring[t] = frag(t);
+        __builtin_amdgcn_sched_group_barrier(0x100, PRE, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int ks = t / (3 * CT), cb = t % CT;
+            const agg_s16x8 bf = ring[t % NB];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(agg_bf16x8, af[ks][rb]),
+                                                                      __builtin_bit_cast(agg_bf16x8, bf), acc[rb][cb],
+                                                                      0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (t + NB < T) {
+                ring[t % NB] = frag(t + NB);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    };
+
+    load_v(0);
+#pragma unroll
+    for (int u = 0; u < NA - 1; ++u) load_a(u, areg[u]);
+    write_v(0);
+    load_v(min(1, psteps - 1));
+    // the trip count is rounded up to a multiple of NA (static register-set indices); stages past the end only
+    // move clamped duplicates and multiply zeros
+    for (int ps0 = 0; ps0 < psteps; ps0 += NA) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int ps = ps0 + u;
+            __syncthreads();              // stage ps is visible; everyone is done reading the other buffer
+            write_v((u + 1) & 1);         // NA is even, so the stage parity is u's
+            __builtin_amdgcn_sched_barrier(0);   // the staging registers are free before they are refilled
+            load_v(min(ps + 2, psteps - 1));
+            load_a(ps + NA - 1, areg[(u + NA - 1) % NA]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(u & 1, areg[u]);
+        }
+    }
+
+    // ---------------- epilogue.  Lane (kq, l15) holds rows rb*16 + kq*4 + r, column cb*16 + l15.
+    if (a.U) {
+        const bool accum = a.beta != 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rw0 + rb * 16 + kq * 4 + r;
+                float* u = a.U + ((long)b * n + min(row, n - 1)) * a.ldu;
+                float old[CT];
+                if (accum) {                     // one batch of unpredicated loads per row (clamped addresses)
+#pragma unroll
+                    for (int cb = 0; cb < CT; ++cb) old[cb] = u[min(cb * 16 + l15, a.C - 1)];
+                }
+#pragma unroll
+                for (int cb = 0; cb < CT; ++cb) {
+                    const int col = cb * 16 + l15;
+                    const float v = accum ? acc[rb][cb][r] + a.beta * old[cb] : acc[rb][cb][r];
+                    if (row < n && col < a.C) u[col] = v;
+                }
+            }
+        return;
+    }
+    // fused GraphConv tail (encoders.py:966-972) in registers: a row lives in the 16 lanes of one kq group
+    const int G = a.g.G, c01 = G == 2 ? a.g.c0[1] : 0x7fffffff;
+    float bias_v[CT];
+    int grp[CT];
+#pragma unroll
+    for (int cb = 0; cb < CT; ++cb) {
+        const int col = cb * 16 + l15;
+        grp[cb] = col >= c01 ? 1 : 0;
+        const float* bp = a.bias.p[grp[cb]];
+        bias_v[cb] = (col < a.C && bp) ? bp[col - a.g.c0[grp[cb]]] : 0.f;
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int node = rw0 + rb * 16 + kq * 4 + r;
+            const bool rv = node < n;
+            const long row = (long)b * n + min(node, n - 1);
+            float u[CT];
+            float ss[2] = {0.f, 0.f};
+            if (a.P) {
+#pragma unroll
+                for (int cb = 0; cb < CT; ++cb) u[cb] = a.P[row * a.ldv + min(cb * 16 + l15, a.C - 1)];
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < CT; ++cb) u[cb] = 0.f;
+            }
+#pragma unroll
+            for (int cb = 0; cb < CT; ++cb) {
+                const int col = cb * 16 + l15;
+                const float v = col < a.C ? acc[rb][cb][r] + bias_v[cb] + u[cb] : 0.f;
+                u[cb] = v;
+                ss[grp[cb]] += v * v;
+            }
+            float inv[2], mean[2] = {0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float t = agg_team_sum(ss[g]);
+                inv[g] = a.normalize ? 1.f / fmaxf(sqrtf(t), AGG_L2_EPS) : 1.f;
+            }
+            float s1[2] = {0.f, 0.f};
+#pragma unroll
+            for (int cb = 0; cb < CT; ++cb) {
+                const int col = cb * 16 + l15;
+                const float v = u[cb] * inv[grp[cb]];
+                u[cb] = v;
+                if (col < a.C) {
+                    if (rv) a.yout.p[grp[cb]][row * a.yout.ld[grp[cb]] + col - a.g.c0[grp[cb]]] = v;
+                    s1[grp[cb]] += a.stats_mode == 1 ? fmaxf(v, 0.f) : v;
+                }
+            }
+            if (rv && l15 == 0 && a.invn)
+                for (int g = 0; g < G; ++g) a.invn[row * G + g] = inv[g];
+            if (a.stats_mode && a.part) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) mean[g] = agg_team_sum(s1[g]) / (float)(g < G ? a.g.w[g] : 1);
+                float m2[2] = {0.f, 0.f};
+#pragma unroll
+                for (int cb = 0; cb < CT; ++cb) {
+                    const int col = cb * 16 + l15;
+                    if (col < a.C) {
+                        float v = u[cb];
+                        if (a.stats_mode == 1) v = fmaxf(v, 0.f);
+                        v -= mean[grp[cb]];
+                        m2[grp[cb]] += v * v;
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) m2[g] = agg_team_sum(m2[g]);
+                if (rv && l15 == 0)
+                    for (int g = 0; g < G; ++g) {
+                        a.part[(row * G + g) * 2 + 0] = mean[g];
+                        a.part[(row * G + g) * 2 + 1] = m2[g];
+                    }
+            }
+        }
+}
+
+constexpr int AGGW_MAX_C = 320;
+static int aggw_ct(int C) {
+    const int ct = (C + 15) / 16;
+    return ct <= 8 ? ct : (ct + 1) & ~1;
+}
+// the wide kernel pays when it fills the chip (>= 2 workgroups per CU) or when the operand is too wide for the
+// panel kernel; it needs the packed adjacency (n >= 128)
+static bool aggw_usable(const PackedAdj* pk, const unsigned short* vs, int B, int n, int C) {
+    if (!pk || !vs || n < 128 || C < 1 || C > AGGW_MAX_C) return false;
+    static const int force = getenv("DP_AGG_WIDE") ? atoi(getenv("DP_AGG_WIDE")) : -1;   // tests: 0 never, 1 always
+    if (force >= 0) return force != 0;
+    return C > 128 || (long)B * ((n + 127) / 128) >= 512;
+}
+
+template <int CT>
+static void launch_aggw(Seq& q, const AggArgs& a, int B) {
+    constexpr int KS = CT <= 8 ? 2 : 1;
+    constexpr size_t lds = (size_t)2 * 3 * CT * KS * 1024;
+    static_assert(lds <= 160 * 1024, "wide aggregation LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate_wide<CT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    AggArgs aa = a;
+    aa.tiles = (a.n + 127) / 128;
+    aa.vs_ct = (a.C + 15) / 16;
+    hipLaunchKernelGGL((k_aggregate_wide<CT>), dim3(aa.tiles * B), dim3(256), lds, q.stream, aa);
+}
+static void dispatch_wide(Seq& q, const AggArgs& a, int B) {
+    switch (aggw_ct(a.C)) {
+#define W(T) case T: launch_aggw<T>(q, a, B); break;
+        W(1) W(2) W(3) W(4) W(5) W(6) W(7) W(8) W(10) W(12) W(14) W(16) W(18) W(20)
+#undef W
+        default: break;
     }
 }
 
@@ -498,7 +782,7 @@ void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int
 int adj_pack_ld(int n) { return (n + 7) & ~7; }
 bool adj_pack_supported(int n, int C) {
     // worth it only for big levels; the bf16 panel of a 32-row tile must fit LDS beside the reduction area
-    return n >= 128 && C >= 1 && C <= 128 &&
+    return n >= 128 && C >= 1 && C <= AGGW_MAX_C &&
            ((size_t)16 * (((n + 511) / 512) * 512 + 8) * 2 + 5 * 16 * 129 * 4 <= 156 * 1024);
 }
 
@@ -548,7 +832,7 @@ static void split3(Seq& q, const float* V, int ldv, unsigned short* Vs, int B, i
 // true when aggregate()/aggregate_rownorm_fwd() will take the packed path for this shape (so a producer may
 // emit the split operand itself)
 bool aggregate_packed_usable(const float* A, int n, int C) {
-    return aggregate_supported(A, n, C, false) && adj_pack_supported(n, C);
+    return adj_pack_supported(n, C) && (C > 128 || aggregate_supported(A, n, C, false));
 }
 
 static void fill_packed(AggArgs& a, const PackedAdj* pk, bool trans, const unsigned short* vs, int n) {
@@ -565,14 +849,38 @@ static void fill_packed(AggArgs& a, const PackedAdj* pk, bool trans, const unsig
 void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ldu, int B, int n, int C, bool trans,
                float beta, const PackedAdj* pk, unsigned short* vs, bool vs_ready) {
     if (!q.ok()) return;
-    if (!aggregate_supported(A, n, C, trans)) {
+    const bool packed = pk && vs && adj_pack_supported(n, C);
+    const bool panel = aggregate_supported(A, n, C, trans);
+    const bool wide = packed && aggw_usable(pk, vs, B, n, C);
+    AggArgs a{};
+    a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = U; a.ldu = ldu; a.beta = beta;
+    if (wide) {
+        if (!vs_ready) split3(q, V, ldv, vs, B, n, C);
+        fill_packed(a, pk, trans, vs, n);
+        dispatch_wide(q, a, B);
+        q.check_launch("aggregate_wide");
+        // fp32 fallback for adjacency that is not bf16-exact, gated on the device flag (no host sync)
+        if (panel) {
+            AggArgs f{};
+            f.A = A; f.V = V; f.ldv = ldv; f.n = n; f.C = C; f.U = U; f.ldu = ldu; f.beta = beta;
+            f.run_if = pk->flag;
+            if (trans) dispatch_ct<true>(q, f, B); else dispatch_ct<false>(q, f, B);
+            q.check_launch("aggregate");
+        } else {
+            const int* keep = q.pred;
+            q.pred = pk->flag;
+            bgemm(q, A, V, U, nullptr, B, n, C, n, n, ldv, ldu, (long)n * n, (long)n * ldv, (long)n * ldu, trans, false,
+                  1.f, beta, 0);
+            q.pred = keep;
+        }
+        return;
+    }
+    if (!panel) {
         bgemm(q, A, V, U, nullptr, B, n, C, n, n, ldv, ldu, (long)n * n, (long)n * ldv, (long)n * ldu, trans, false,
               1.f, beta, 0);
         return;
     }
-    AggArgs a{};
-    a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = U; a.ldu = ldu; a.beta = beta;
-    if (pk && vs && adj_pack_supported(n, C)) {
+    if (packed) {
         if (!vs_ready) split3(q, V, ldv, vs, B, n, C);
         fill_packed(a, pk, trans, vs, n);
     }
@@ -592,8 +900,15 @@ bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, cons
     a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = nullptr;
     a.P = P; a.bias = bias; a.g = g; a.yout = yout; a.invn = invn; a.part = part;
     a.normalize = normalize; a.stats_mode = stats_mode;
-    if (pk && vs && adj_pack_supported(n, C)) {
-        if (!vs_ready) split3(q, V, ldv, vs, B, n, C);
+    const bool packed = pk && vs && adj_pack_supported(n, C);
+    if (packed && !vs_ready) split3(q, V, ldv, vs, B, n, C);
+    if (packed && aggw_usable(pk, vs, B, n, C)) {
+        AggArgs w = a;
+        fill_packed(w, pk, false, vs, n);
+        dispatch_wide(q, w, B);
+        q.check_launch("aggregate_wide_rownorm");
+        a.run_if = pk->flag;               // fp32 fallback, runs only for adjacency that is not bf16-exact
+    } else if (packed) {
         fill_packed(a, pk, false, vs, n);
     }
     dispatch_ct<false>(q, a, B);

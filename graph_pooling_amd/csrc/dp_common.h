@@ -30,6 +30,7 @@ struct Seq {
     size_t ws_off;
     int err;             // 0, DP_ERR_* (<0) or hipError_t (>0)
     bool dry;            // dry run: only walk the allocations (workspace sizing), launch nothing
+    const int* pred = nullptr;   // when set: bgemm launches exit at once unless *pred != 0 (device-side fallback gate)
 
     Seq(hipStream_t s, void* w, size_t wb) : stream(s), ws((char*)w), ws_bytes(wb), ws_off(0), err(0), dry(false) {}
     static Seq sizing() {

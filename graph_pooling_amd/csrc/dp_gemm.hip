@@ -266,6 +266,7 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
 // One launch, up to GEMM_GROUP_MAX independent problems (same batch count): the workgroup finds its
 // problem from the tile prefix, then runs the body for that problem's transposes.
 struct GemmGroupArgs {
+    const int* pred;     // non-null: run only when *pred != 0
     int count;
     int tile0[GEMM_GROUP_MAX + 1];
     GemmArgs p[GEMM_GROUP_MAX];
@@ -279,6 +280,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void bgemm_kernel(GemmGroupArgs g) {
     __shared__ __attribute__((aligned(16))) float
         lds[cmax(lds_size<BM, true>(), lds_size<BM, false>()) + cmax(lds_size<BN, true>(), lds_size<BN, false>()) + 8];
+    if (g.pred && __builtin_amdgcn_readfirstlane(*g.pred) == 0) return;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < GEMM_GROUP_MAX; ++i)
@@ -321,6 +323,7 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
         return;
     }
     GemmGroupArgs g{};
+    g.pred = q.pred;
     int maxN = 0;
     for (int i = 0; i < count; ++i) {
         const GemmDesc& s = d[i];

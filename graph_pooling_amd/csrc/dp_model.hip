@@ -443,7 +443,7 @@ size_t vs_elems(const dp_encoder_cfg& c) {
     if (!adj_pack_supported(c.N, 1)) return 64;
     const LevelInfo li = level_info(c, 0);
     int cm = li.cmax > li.K ? li.cmax : li.K;
-    if (cm > 128) cm = 128;
+    if (cm > 320) cm = 320;     // widest operand the packed kernels take (dp_agg.hip AGGW_MAX_C)
     return split3_elems(c.B, c.N, cm) + 64;
 }
 

@@ -123,7 +123,32 @@ struct BnApplyArgs {
     GroupPtrs xout;
     int B, n;
     int relu;
+    int stats_ready;     // big batches: (mu, rstd) were finalised by k_bn_finalize, read them instead of combining
 };
+// big batches: one team per (node, group) combines the B partials once (the apply kernel would otherwise repeat
+// that B-term reduction in every one of the B rows of the node)
+__global__ __launch_bounds__(256) void k_bn_finalize(BnApplyArgs a) {
+    const int tl = threadIdx.x & 15;
+    const long it = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (it >= (long)a.n * a.g.G) return;
+    const int g = (int)(it % a.g.G);
+    const int w = a.g.w[g];
+    const long pstride = (long)a.n * a.g.G * 2;
+    const float* p = a.part + it * 2;
+    float sm = 0.f;
+    for (int b = tl; b < a.B; b += 16) sm += p[b * pstride];
+    const float mu = team_sum(sm) / (float)a.B;
+    float s2 = 0.f;
+    for (int b = tl; b < a.B; b += 16) {
+        const float d = p[b * pstride] - mu;
+        s2 += p[b * pstride + 1] + (float)w * d * d;
+    }
+    const float var = team_sum(s2) / ((float)a.B * (float)w);
+    if (tl == 0) {
+        a.stats[it * 2] = mu;
+        a.stats[it * 2 + 1] = 1.0f / sqrtf(var + BN_EPS);
+    }
+}
 __global__ __launch_bounds__(256) void k_bn_apply_fwd(BnApplyArgs a) {
     const int tl = threadIdx.x & 15;
     const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -135,7 +160,10 @@ __global__ __launch_bounds__(256) void k_bn_apply_fwd(BnApplyArgs a) {
         const int node = (int)(row % a.n);
         const int w = a.g.w[g];
         float mu = 0.f, rstd = 1.f;
-        if (a.part) {
+        if (a.part && a.stats_ready) {
+            mu = a.stats[((long)node * a.g.G + g) * 2];
+            rstd = a.stats[((long)node * a.g.G + g) * 2 + 1];
+        } else if (a.part) {
             const long pstride = (long)a.n * a.g.G * 2;
             const float* p = a.part + ((long)node * a.g.G + g) * 2;
             float sm = 0.f;
@@ -164,7 +192,12 @@ __global__ __launch_bounds__(256) void k_bn_apply_fwd(BnApplyArgs a) {
 void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* part, float* stats, RowGroups g, GroupPtrs xout,
                   int B, int n, int relu) {
     if (!q.ok()) return;
-    BnApplyArgs a{Y, ldy, part, stats, g, xout, B, n, relu};
+    BnApplyArgs a{Y, ldy, part, stats, g, xout, B, n, relu, 0};
+    if (part && B > 32) {
+        hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)(((long)n * g.G + 15) / 16)), dim3(256), 0, q.stream, a);
+        q.check_launch("bn_finalize");
+        a.stats_ready = 1;
+    }
     hipLaunchKernelGGL(k_bn_apply_fwd, dim3(team_grid((long)B * n * g.G)), dim3(256), 0, q.stream, a);
     q.check_launch("bn_apply_fwd");
 }

@@ -71,7 +71,8 @@ int dp_adj_aggregate(const float* adj, const float* V, int ldv, float* U, int ld
  * dp_adj_pack_ld(n) elements) plus a device flag that is 0 iff every entry is exactly representable in bf16
  * (always true for the 0/1 adjacency of graph_sampler.py:26).  dp_adj_aggregate_packed then computes the same
  * U = op(adj)·V with V split exactly into three bf16 planes (fp32-grade result, bf16 MFMA rate, half the
- * adjacency bytes) when the flag is 0, and with the fp32 loop otherwise — decided on the device, no sync. */
+ * adjacency bytes) when the flag is 0, and with the fp32 loop otherwise — decided on the device, no sync.
+ * `flag` points at a 256-byte, 16-byte-aligned device block: dp_adj_pack clears all of it and sets only word 0. */
 int dp_adj_pack_ld(int n);
 size_t dp_adj_pack_bytes(int B, int n);            /* bytes of ONE packed copy */
 int dp_adj_pack(const float* adj, void* packed, void* packed_t, int* flag, int B, int n, void* stream);

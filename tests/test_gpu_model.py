@@ -102,6 +102,8 @@ def _oracle_run(params, x, adj, nn_, label, linkpred, num_pooling=1):
     (20, 500, 89, 20, 2, 0.1, 0.02, False, "S-DD"),      # BASELINE configs[1] shape (the metric's workload)
     (20, 500, 89, 20, 2, 0.1, 0.02, True, "S-DD+link"),
     (5, 67, 11, 12, 3, 0.25, 0.15, True, "odd"),
+    (3, 256, 16, 20, 3, 0.6, 0.05, True, "wide-K"),       # K = 154 clusters: operands wider than 128 -> wide bf16 kernel
+    (132, 512, 8, 12, 2, 0.05, 0.02, False, "big-B"),     # 528 row tiles of 128: wide kernel with the fused tail
 ])
 def test_softpool_against_oracle_synthetic(B, N, F_, H, Cc, ratio, p, linkpred, tag):
     n_min = max(1, N // 10)

@@ -127,7 +127,8 @@ def _packed_aggregate(lib, adj, V, C, trans, beta, U0):
 
 @pytest.mark.parametrize("trans", [0, 1])
 @pytest.mark.parametrize("B,n,C", [(3, 128, 5), (20, 500, 40), (4, 500, 70), (2, 1024, 33), (2, 516, 128),
-                                   (2, 200, 50), (3, 131, 17), (2, 512, 276), (1, 1024, 256), (2, 260, 130)])
+                                   (2, 200, 50), (3, 131, 17), (2, 512, 276), (1, 1024, 256), (2, 260, 130),
+                                   (130, 500, 40), (64, 1024, 48), (2, 300, 320), (3, 129, 150), (1, 2100, 200)])
 def test_packed_aggregate_binary_adjacency_is_fp32_exact(lib, trans, B, n, C):
     """0/1 adjacency: the bf16 x (hi+mid+lo) path must agree with the fp64 product to fp32 rounding — every
     product is exact, only the fp32 accumulation order differs."""
@@ -155,9 +156,10 @@ def test_packed_aggregate_other_bf16_exact_values(lib):
 
 
 @pytest.mark.parametrize("trans", [0, 1])
-def test_packed_aggregate_falls_back_when_not_bf16_exact(lib, trans):
-    # a single entry with low mantissa bits set flips the device flag: the fp32 loop must run (and be right)
-    B, n, C = 2, 260, 24
+@pytest.mark.parametrize("B,n,C", [(2, 260, 24), (2, 260, 150), (2, 258, 150), (140, 512, 24)])
+def test_packed_aggregate_falls_back_when_not_bf16_exact(lib, trans, B, n, C):
+    # a single entry with low mantissa bits set flips the device flag: the fp32 loop must run (and be right);
+    # the wide shapes (C > 128, or >= 512 row tiles) take it as a flag-gated second launch
     g = torch.Generator().manual_seed(2)
     adj = (torch.rand(B, n, n, generator=g) < 0.1).float()
     adj[1, 200, 37] = 0.3                                     # not representable in bf16
