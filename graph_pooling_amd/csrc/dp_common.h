@@ -214,6 +214,34 @@ void small_gcn_bwd(Seq& q, const float* adj, const float* xin, int ldxin, const 
                    float* db, long slab_stride, int B, int n, int din, int dout, int add_self, int has_bn,
                    int has_relu);
 
+// (dp_head.hip) last-level max readout + pred_model in one launch per direction
+struct HeadArgs {
+    const float* Z;          // last level's embedding [B, n, ldz] for the in-kernel max readout, or null
+    int ldz, n, rw, featoff; // readout width and its column offset in the feature vector
+    int* argmax;             // [B, lda]
+    int lda;
+    const float* params;
+    int n_pred;
+    int dims[DP_MAX_PRED + 2];
+    long w_off[DP_MAX_PRED + 1], b_off[DP_MAX_PRED + 1];
+    float* hid[DP_MAX_PRED + 2];   // hid[0] = features [B, dims[0]], hid[i] = post-ReLU activations, hid[n_pred] = ypred
+    int B;
+};
+struct HeadBwdArgs {
+    HeadArgs h;              // dims / offsets / saved activations (hid[] read-only here)
+    const float* d_ypred;    // [B, dims[n_pred]]
+    float* grads;            // flat gradient buffer (pred_model entries are written, not accumulated)
+    int n_levels;
+    struct Level {
+        float* dZ;           // zero-initialised [B, n, ldz] (already offset to the first readout column)
+        const int* argmax;
+        int lda, n, ldz, rw, featoff;
+    } lv[DP_MAX_LEVELS + 1];
+};
+bool head_supported(const HeadArgs& a);
+void head_fwd(Seq& q, const HeadArgs& a);
+void head_bwd(Seq& q, const HeadBwdArgs& a);
+
 // (dp_linkpred.hip)
 void linkpred_fwd(Seq& q, const float* S, int lds, const float* adj, const int* num_nodes, float* loss_out,
                   int B, int n, int K);

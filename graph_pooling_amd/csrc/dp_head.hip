@@ -1,0 +1,328 @@
+// The prediction head of the encoders in two launches instead of ten:
+//   forward : last-level max readout (encoders.py:1069-1071 / 1296-1298) + pred_model, the Linear/ReLU stack of
+//             build_pred_layers (encoders.py:1027-1041) — per graph independent, one workgroup per graph;
+//   backward: the whole pred_model backward (weight, bias and input gradients) + the max-readout scatter of every
+//             level — one workgroup for the batch, so the weight gradients are plain deterministic sums over b.
+// At B = 20 these were 3 + 7 kernels of 4-6 us each, all of them at the launch floor.
+#include "dp_common.h"
+
+namespace dp {
+
+constexpr int HEAD_FWD_LDS_FLOATS = 30 * 1024;    // weights + biases + two activation vectors + readout scratch
+constexpr int HEAD_BWD_LDS_FLOATS = 38 * 1024;    // weights + saved activations of the batch + two gradient blocks
+
+__device__ inline float head_wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// dst[i] = src[i] for i < cnt, 16 loads per thread in flight (clamped addresses, no branch around the loads)
+template <int NT>
+__device__ inline void head_stage(float* dst, const float* src, int cnt) {
+    for (int e0 = 0; e0 < cnt; e0 += NT * 16) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = src[min(e0 + u * NT + (int)threadIdx.x, cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = e0 + u * NT + (int)threadIdx.x;
+            if (i < cnt) dst[i] = t[u];
+        }
+    }
+}
+
+struct HeadSizes {
+    int wtot, btot, mx, hsum;      // weight floats, bias floats, widest layer, sum of dims[0..L]
+};
+__host__ __device__ inline HeadSizes head_sizes(const HeadArgs& a) {
+    HeadSizes z{0, 0, 0, 0};
+    for (int i = 0; i < a.n_pred; ++i) {
+        z.wtot += a.dims[i] * a.dims[i + 1];
+        z.btot += a.dims[i + 1];
+    }
+    for (int i = 0; i <= a.n_pred; ++i) {
+        z.mx = a.dims[i] > z.mx ? a.dims[i] : z.mx;
+        z.hsum += a.dims[i];
+    }
+    return z;
+}
+
+// Both kernels are latency problems, not throughput problems (a 120-50-2 MLP on 20 graphs): every global operand is
+// requested up front in bulk, coalesced loops into LDS, and all arithmetic then runs out of LDS.
+
+// ------------------------------------------------------------------ forward  (one workgroup per graph)
+__global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
+    extern __shared__ float lds[];
+    const HeadSizes z = head_sizes(a);
+    float* Wl = lds;                       // all layers' weights, layer after layer
+    float* bl = Wl + z.wtot;               // all biases (zeros where a layer has none)
+    float* h0 = bl + z.btot;               // activations, ping
+    float* h1 = h0 + z.mx;                 // pong
+    float* sv = h1 + z.mx;                 // readout partials [4][64] values
+    int* si = reinterpret_cast<int*>(sv + 256);
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* feat = a.hid[0] + (long)b * a.dims[0];
+    // (1) readout loads go out first (8 rows per thread in flight, clamped addresses, no branches) ...
+    constexpr int RU = 8;
+    float zv[RU];
+    const bool one_pass = a.Z && a.rw <= 64 && a.n <= 4 * RU;
+    if (one_pass) {
+        const float* zc = a.Z + (long)b * a.n * a.ldz + min(lane, a.rw - 1);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) zv[u] = zc[(long)min(wave + 4 * u, a.n - 1) * a.ldz];
+    }
+    // (2) ... then the weights, biases and lower-level features stream into LDS behind them
+    {
+        int wo = 0, bo = 0;
+        for (int i = 0; i < a.n_pred; ++i) {
+            const int cnt = a.dims[i] * a.dims[i + 1];
+            const float* W = a.params + a.w_off[i];
+            head_stage<256>(Wl + wo, W, cnt);
+            for (int e = threadIdx.x; e < a.dims[i + 1]; e += 256)
+                bl[bo + e] = a.b_off[i] >= 0 ? a.params[a.b_off[i] + e] : 0.f;
+            wo += cnt;
+            bo += a.dims[i + 1];
+        }
+    }
+    for (int k = threadIdx.x; k < a.dims[0]; k += 256)
+        if (!a.Z || k < a.featoff || k >= a.featoff + a.rw) h0[k] = feat[k];
+    if (a.Z) {
+        // unmasked max over the nodes of the last level; ties -> lowest row (torch CPU max).  Four row groups x 64
+        // columns per pass, combined through LDS.
+        for (int c0 = 0; c0 < a.rw; c0 += 64) {
+            const int c = c0 + lane;
+            float best = -INFINITY;
+            int bi = -1;
+            if (one_pass) {
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int r = wave + 4 * u;
+                    if (r < a.n && zv[u] > best) {
+                        best = zv[u];
+                        bi = r;
+                    }
+                }
+            } else if (c < a.rw) {
+                const float* zc = a.Z + (long)b * a.n * a.ldz + c;
+#pragma unroll 4
+                for (int r = wave; r < a.n; r += 4) {
+                    const float v = zc[(long)r * a.ldz];
+                    if (v > best) {
+                        best = v;
+                        bi = r;
+                    }
+                }
+            }
+            sv[wave * 64 + lane] = best;
+            si[wave * 64 + lane] = bi;
+            __syncthreads();
+            if (wave == 0 && c < a.rw) {
+                for (int k = 1; k < 4; ++k) {
+                    const float v = sv[k * 64 + lane];
+                    const int i2 = si[k * 64 + lane];
+                    if (i2 >= 0 && (v > best || (v == best && i2 < bi))) {
+                        best = v;
+                        bi = i2;
+                    }
+                }
+                h0[a.featoff + c] = best;
+                feat[a.featoff + c] = best;
+                a.argmax[(long)b * a.lda + c] = bi;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    float* cur = h0;
+    float* nxt = h1;
+    int wo = 0, bo = 0;
+    for (int i = 0; i < a.n_pred; ++i) {
+        const int din = a.dims[i], dout = a.dims[i + 1];
+        const bool last = i == a.n_pred - 1;
+        float* out = a.hid[i + 1] + (long)b * dout;
+        // lane = output (64 per pass), the four waves split k; partial sums meet in LDS.  (A wave-per-output dot
+        // product costs a 6-step cross-lane reduction per output: 13 serial ones for the 50-wide hidden layer.)
+        for (int j0 = 0; j0 < dout; j0 += 64) {
+            const int j = j0 + lane;
+            const int kq = (din + 3) / 4, kb = wave * kq, ke = min(din, kb + kq);
+            float s = 0.f;
+            if (j < dout) {
+                const float* w = Wl + wo + j * din;
+#pragma unroll 8
+                for (int k = kb; k < ke; ++k) s += cur[k] * w[k];
+            }
+            sv[wave * 64 + lane] = s;
+            __syncthreads();
+            if (wave == 0 && j < dout) {
+                s = sv[lane] + sv[64 + lane] + sv[128 + lane] + sv[192 + lane] + bl[bo + j];
+                if (!last) s = fmaxf(s, 0.f);
+                nxt[j] = s;
+                out[j] = s;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        float* t = cur; cur = nxt; nxt = t;
+        wo += din * dout;
+        bo += dout;
+    }
+}
+
+static size_t head_fwd_lds_floats(const HeadArgs& a) {
+    const HeadSizes z = head_sizes(a);
+    return (size_t)z.wtot + z.btot + 2 * z.mx + 512;
+}
+void head_fwd(Seq& q, const HeadArgs& a) {
+    if (!q.ok()) return;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  HEAD_FWD_LDS_FLOATS * (int)sizeof(float));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_head_fwd, dim3(a.B), dim3(256), head_fwd_lds_floats(a) * sizeof(float), q.stream, a);
+    q.check_launch("head_fwd");
+}
+
+// ------------------------------------------------------------------ backward
+// Workgroup w owns a slice of HEAD_SLICE input columns of the FIRST Linear (the wide one: 120 readout features against
+// 50 and 2 above it): its weight-gradient columns, its share of d(features) and the max-readout scatter of those
+// features.  The layers above are a few hundred MACs per graph; every workgroup recomputes them from LDS instead of
+// waiting for a neighbour (no inter-workgroup dependency), and workgroup 0 stores their gradients.  All sums over the
+// batch are plain loops in b: deterministic.
+constexpr int HEAD_SLICE = 16;
+__global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
+    extern __shared__ float lds[];
+    const int B = a.h.B, L = a.h.n_pred;
+    const int d0 = a.h.dims[0], d1 = a.h.dims[1];
+    const int k0 = blockIdx.x * HEAD_SLICE, ks = min(HEAD_SLICE, d0 - k0);
+    int wup = 0, hup = 0, mx = 0;                 // floats of the upper layers' weights / saved inputs; widest upper dim
+    for (int i = 1; i < L; ++i) {
+        wup += a.h.dims[i] * a.h.dims[i + 1];
+        hup += a.h.dims[i];
+    }
+    for (int i = 1; i <= L; ++i) mx = max(mx, a.h.dims[i]);
+    float* Wu = lds;                              // upper weights, layer 1 first
+    float* Hu = Wu + wup;                         // saved inputs of layers 1..L-1, [B x dims[i]] each
+    float* W0 = Hu + (long)B * hup;               // [d1][ks] slice of the first layer's weight
+    float* F0 = W0 + d1 * HEAD_SLICE;             // [B][ks] slice of the features
+    float* g0 = F0 + B * HEAD_SLICE;              // gradient ping / pong [B x mx]
+    float* g1 = g0 + (long)B * mx;
+    {
+        int wo = 0, ho = 0;
+        for (int i = 1; i < L; ++i) {
+            const int cnt = a.h.dims[i] * a.h.dims[i + 1];
+            const float* W = a.h.params + a.h.w_off[i];
+            head_stage<256>(Wu + wo, W, cnt);
+            head_stage<256>(Hu + ho, a.h.hid[i], B * a.h.dims[i]);
+            wo += cnt;
+            ho += B * a.h.dims[i];
+        }
+        const float* W = a.h.params + a.h.w_off[0];
+        for (int e = threadIdx.x; e < d1 * ks; e += 256) W0[(e / ks) * HEAD_SLICE + e % ks] = W[(long)(e / ks) * d0 + k0 + e % ks];
+        const float* f = a.h.hid[0];
+        for (int e = threadIdx.x; e < B * ks; e += 256) F0[(e / ks) * HEAD_SLICE + e % ks] = f[(long)(e / ks) * d0 + k0 + e % ks];
+        for (int e = threadIdx.x; e < B * a.h.dims[L]; e += 256) g0[e] = a.d_ypred[e];
+    }
+    __syncthreads();
+    float* go = g0;
+    float* gi = g1;
+    int wo = wup, ho = B * hup;
+    for (int i = L - 1; i >= 1; --i) {
+        const int din = a.h.dims[i], dout = a.h.dims[i + 1];
+        wo -= din * dout;
+        ho -= B * din;
+        const float* W = Wu + wo;
+        const float* hin = Hu + ho;
+        if (blockIdx.x == 0) {
+            float* dW = a.grads + a.h.w_off[i];
+            for (int e = threadIdx.x; e < dout * din; e += 256) {
+                const int j = e / din, k = e % din;
+                float s = 0.f;
+#pragma unroll 8
+                for (int b = 0; b < B; ++b) s += go[b * dout + j] * hin[b * din + k];
+                dW[e] = s;
+            }
+            if (a.h.b_off[i] >= 0)
+                for (int j = threadIdx.x; j < dout; j += 256) {
+                    float s = 0.f;
+#pragma unroll 8
+                    for (int b = 0; b < B; ++b) s += go[b * dout + j];
+                    a.grads[a.h.b_off[i] + j] = s;
+                }
+        }
+        // gi[b][k] = relu'(hin) * sum_j go[b][j] W[j][k]   (hin = relu(.), so hin > 0 decides)
+        for (int e = threadIdx.x; e < B * din; e += 256) {
+            const int b = e / din, k = e % din;
+            float s = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < dout; ++j) s += go[b * dout + j] * W[j * din + k];
+            gi[e] = hin[e] > 0.f ? s : 0.f;
+        }
+        __syncthreads();
+        float* t = go; go = gi; gi = t;
+    }
+    // first layer, this workgroup's columns: go is [B x d1]
+    float* dW = a.grads + a.h.w_off[0];
+    for (int e = threadIdx.x; e < d1 * ks; e += 256) {
+        const int j = e / ks, kk = e % ks;
+        float s = 0.f;
+#pragma unroll 8
+        for (int b = 0; b < B; ++b) s += go[b * d1 + j] * F0[b * HEAD_SLICE + kk];
+        dW[(long)j * d0 + k0 + kk] = s;
+    }
+    if (blockIdx.x == 0 && a.h.b_off[0] >= 0)
+        for (int j = threadIdx.x; j < d1; j += 256) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int b = 0; b < B; ++b) s += go[b * d1 + j];
+            a.grads[a.h.b_off[0] + j] = s;
+        }
+    // d(features) of the slice and its max-readout scatter: dZ[b, argmax, f] += dfeat  (dZ zero-initialised by the caller)
+    for (int e = threadIdx.x; e < B * ks; e += 256) {
+        const int b = e / ks, kk = e % ks, k = k0 + kk;
+        float s = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < d1; ++j) s += go[b * d1 + j] * W0[j * HEAD_SLICE + kk];
+        for (int lv = 0; lv < a.n_levels; ++lv) {
+            const HeadBwdArgs::Level& t = a.lv[lv];
+            const int f = k - t.featoff;
+            if (f >= 0 && f < t.rw) {
+                const int r = t.argmax[(long)b * t.lda + f];
+                if (r >= 0) t.dZ[((long)b * t.n + r) * t.ldz + f] += s;
+            }
+        }
+    }
+}
+
+static size_t head_bwd_lds_floats(const HeadArgs& a) {
+    size_t wup = 0, hup = 0, mx = 0;
+    for (int i = 1; i < a.n_pred; ++i) {
+        wup += (size_t)a.dims[i] * a.dims[i + 1];
+        hup += a.dims[i];
+    }
+    for (int i = 1; i <= a.n_pred; ++i) mx = (size_t)a.dims[i] > mx ? a.dims[i] : mx;
+    return wup + (size_t)a.B * hup + (size_t)a.dims[1] * HEAD_SLICE + (size_t)a.B * HEAD_SLICE + 2 * (size_t)a.B * mx;
+}
+
+bool head_supported(const HeadArgs& a) {
+    if (a.n_pred < 1 || a.B < 1 || a.B > 1024) return false;
+    // everything the kernels touch repeatedly must fit LDS (they are latency-, not throughput-shaped)
+    return head_fwd_lds_floats(a) <= HEAD_FWD_LDS_FLOATS && head_bwd_lds_floats(a) <= HEAD_BWD_LDS_FLOATS;
+}
+
+void head_bwd(Seq& q, const HeadBwdArgs& a) {
+    if (!q.ok()) return;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  HEAD_BWD_LDS_FLOATS * (int)sizeof(float));
+        attr = true;
+    }
+    const int slices = (a.h.dims[0] + HEAD_SLICE - 1) / HEAD_SLICE;
+    hipLaunchKernelGGL(k_head_bwd, dim3(slices), dim3(256), head_bwd_lds_floats(a.h) * sizeof(float), q.stream, a);
+    q.check_launch("head_bwd");
+}
+
+}  // namespace dp

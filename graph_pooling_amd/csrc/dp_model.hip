@@ -447,6 +447,32 @@ size_t vs_elems(const dp_encoder_cfg& c) {
     return split3_elems(c.B, c.N, cm) + 64;
 }
 
+// pred_model (+ the last level's readout when that level is a pooled, unmasked one) as one launch
+HeadArgs head_args(const dp_encoder_cfg& c, const SaveLayout& sv, const float* params, float* ypred) {
+    HeadArgs h{};
+    h.params = params;
+    h.n_pred = c.n_pred;
+    h.B = c.B;
+    for (int i = 0; i <= c.n_pred; ++i) h.dims[i] = c.pred_dims[i];
+    for (int i = 0; i < c.n_pred; ++i) {
+        h.w_off[i] = c.pred_w_off[i];
+        h.b_off[i] = c.pred_b_off[i];
+        h.hid[i] = sv.hid[i];
+    }
+    h.hid[c.n_pred] = ypred;
+    return h;
+}
+bool head_usable(const dp_encoder_cfg& c) {
+    if (c.readout != 0) return false;
+    static const bool off = getenv("DP_NO_HEAD_FUSION") != nullptr;
+    if (off) return false;
+    HeadArgs h{};
+    h.n_pred = c.n_pred;
+    h.B = c.B;
+    for (int i = 0; i <= c.n_pred; ++i) h.dims[i] = c.pred_dims[i];
+    return head_supported(h);
+}
+
 // shared allocation walk for the forward (also used for sizing)
 Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
     size_t maxPU = 0, maxPart = 0, maxLog = 0;
@@ -481,6 +507,8 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
     const PackedAdj* pkp = sv.pkA ? &pk0 : nullptr;
     if (pkp) adj_pack(q, adj, sv.pkA, sv.pkAt, sv.pk_flag, B, c.N, sv.pk_ld);
     int featoff = 0;
+    const bool fused_head = head_usable(c);
+    HeadArgs head = head_args(c, sv, params, ypred);
     for (int j = 0; j <= P; ++j) {
         const LevelInfo li = level_info(c, j);
         const LevelSave& lv = sv.lv[j];
@@ -493,8 +521,13 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
         if (c.readout == 0) {
             const int rw = readout_width(c, li);
             const float* zsrc = (c.flags & DP_F_LAST_ONLY) ? lv.Ze + li.coff_e[li.L - 1] : lv.Ze;
-            masked_max_fwd(q, zsrc, li.D, c.mask_readout ? nn_j : nullptr, sv.feat + featoff, ldfeat, lv.argmax, rw, B,
-                           li.n, rw);
+            if (fused_head && j == P && j > 0) {          // pooled levels are unmasked: the head kernel reads it
+                head.Z = zsrc; head.ldz = li.D; head.n = li.n; head.rw = rw; head.featoff = featoff;
+                head.argmax = lv.argmax; head.lda = rw;
+            } else {
+                masked_max_fwd(q, zsrc, li.D, c.mask_readout ? nn_j : nullptr, sv.feat + featoff, ldfeat, lv.argmax,
+                               rw, B, li.n, rw);
+            }
             featoff += rw;
         } else {
             mask_rows(q, lv.Ze, li.D, sv.Zm, li.D, nn_j, B, li.n, li.D);
@@ -527,6 +560,10 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
         }
     }
     // pred_model
+    if (fused_head) {
+        head_fwd(q, head);
+        return q.err;
+    }
     for (int i = 0; i < c.n_pred; ++i) {
         const bool lastl = i == c.n_pred - 1;
         float* out = lastl ? ypred : sv.hid[i + 1];
@@ -594,37 +631,57 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     zero_fill(q, q.ws + zero_begin, zero_end - zero_begin);
     // the slabs receive atomic adds (bias sums) and leave split-K rows unused: zero them once per backward
     zero_fill(q, slabs, align256((size_t)B * KS * c.n_graph_params * sizeof(float)));
-    // ---- pred_model backward
-    for (int i = c.n_pred - 1; i >= 0; --i) {
-        const int din = c.pred_dims[i], dout = c.pred_dims[i + 1];
-        {
-            GemmDesc d[2] = {
-                {dh[i + 1], sv.hid[i], grads + c.pred_w_off[i], nullptr, dout, din, B, dout, din, din, 0, 0, 0, true,
-                 false, 1.f, 0.f, 0},
-                {dh[i + 1], PW(params, c.pred_w_off[i]), dh[i], nullptr, B, din, dout, dout, din, din, 0, 0, 0, false,
-                 false, 1.f, 0.f, 0}};
-            bgemm_group(q, d, 2, 1);
-        }
-        if (c.pred_b_off[i] >= 0) colsum_batched(q, dh[i + 1], dout, 0, B, dout, grads + c.pred_b_off[i], 0, 1);
-        if (i > 0) relu_bwd_inplace(q, dh[i], sv.hid[i], (long)B * din);
-    }
-    const float* dfeat = dh[0];
-    const int ldfeat = c.pred_dims[0];
-    // ---- readout backward -> dZe_j
-    int featoff = 0;
-    for (int j = 0; j <= P; ++j) {
-        const LevelInfo li = level_info(c, j);
-        if (c.readout == 0) {
+    const bool fused_head = head_usable(c);
+    if (fused_head) {
+        // pred_model backward + the max-readout scatter of every level in one launch
+        HeadBwdArgs hb{};
+        hb.h = head_args(c, sv, params, nullptr);
+        hb.d_ypred = d_ypred;
+        hb.grads = grads;
+        int featoff = 0;
+        for (int j = 0; j <= P; ++j) {
+            const LevelInfo li = level_info(c, j);
             const int rw = readout_width(c, li);
-            float* dz = (c.flags & DP_F_LAST_ONLY) ? gr[j].dZe + li.coff_e[li.L - 1] : gr[j].dZe;
-            masked_max_bwd(q, dfeat + featoff, ldfeat, sv.lv[j].argmax, rw, dz, li.D, B, li.n, rw);
+            HeadBwdArgs::Level& s = hb.lv[hb.n_levels++];
+            s.dZ = (c.flags & DP_F_LAST_ONLY) ? gr[j].dZe + li.coff_e[li.L - 1] : gr[j].dZe;
+            s.argmax = sv.lv[j].argmax;
+            s.lda = rw; s.n = li.n; s.ldz = li.D; s.rw = rw; s.featoff = featoff;
             featoff += rw;
-        } else {
-            set2set_bwd(q, sv.Zm, li.D, PW(params, c.s2s_off[0]), PW(params, c.s2s_off[1]), PW(params, c.s2s_off[2]),
-                        PW(params, c.s2s_off[3]), PW(params, c.s2s_off[4]), PW(params, c.s2s_off[5]), sv.feat, dfeat,
-                        dZm, li.D, grads + c.s2s_off[0], grads + c.s2s_off[1], grads + c.s2s_off[2],
-                        grads + c.s2s_off[3], grads + c.s2s_off[4], grads + c.s2s_off[5], B, li.n, li.D, sv.s2s);
-            mask_rows(q, dZm, li.D, gr[j].dZe, li.D, num_nodes, B, li.n, li.D);
+        }
+        head_bwd(q, hb);
+    } else {
+        // ---- pred_model backward
+        for (int i = c.n_pred - 1; i >= 0; --i) {
+            const int din = c.pred_dims[i], dout = c.pred_dims[i + 1];
+            {
+                GemmDesc d[2] = {
+                    {dh[i + 1], sv.hid[i], grads + c.pred_w_off[i], nullptr, dout, din, B, dout, din, din, 0, 0, 0, true,
+                     false, 1.f, 0.f, 0},
+                    {dh[i + 1], PW(params, c.pred_w_off[i]), dh[i], nullptr, B, din, dout, dout, din, din, 0, 0, 0, false,
+                     false, 1.f, 0.f, 0}};
+                bgemm_group(q, d, 2, 1);
+            }
+            if (c.pred_b_off[i] >= 0) colsum_batched(q, dh[i + 1], dout, 0, B, dout, grads + c.pred_b_off[i], 0, 1);
+            if (i > 0) relu_bwd_inplace(q, dh[i], sv.hid[i], (long)B * din);
+        }
+        const float* dfeat = dh[0];
+        const int ldfeat = c.pred_dims[0];
+        // ---- readout backward -> dZe_j
+        int featoff = 0;
+        for (int j = 0; j <= P; ++j) {
+            const LevelInfo li = level_info(c, j);
+            if (c.readout == 0) {
+                const int rw = readout_width(c, li);
+                float* dz = (c.flags & DP_F_LAST_ONLY) ? gr[j].dZe + li.coff_e[li.L - 1] : gr[j].dZe;
+                masked_max_bwd(q, dfeat + featoff, ldfeat, sv.lv[j].argmax, rw, dz, li.D, B, li.n, rw);
+                featoff += rw;
+            } else {
+                set2set_bwd(q, sv.Zm, li.D, PW(params, c.s2s_off[0]), PW(params, c.s2s_off[1]), PW(params, c.s2s_off[2]),
+                            PW(params, c.s2s_off[3]), PW(params, c.s2s_off[4]), PW(params, c.s2s_off[5]), sv.feat, dfeat,
+                            dZm, li.D, grads + c.s2s_off[0], grads + c.s2s_off[1], grads + c.s2s_off[2],
+                            grads + c.s2s_off[3], grads + c.s2s_off[4], grads + c.s2s_off[5], B, li.n, li.D, sv.s2s);
+                mask_rows(q, dZm, li.D, gr[j].dZe, li.D, num_nodes, B, li.n, li.D);
+            }
         }
     }
     // ---- levels, top down
