@@ -36,10 +36,11 @@ WORKLOADS = {
                name="S-DD: DD-shaped padded batch, B=20/GPU, N_max=500, F=89, H=E=20, K=50, L=3, 1 pool"),
     "enzymes": dict(B=20, N=100, F=3, H=20, C=6, ratio=0.1, p=0.10, n_min=10, onehot=True,
                     name="S-ENZ: ENZYMES-shaped padded batch, B=20/GPU, N=100, F=3, H=E=20, K=10"),
-    "er": dict(B=256, N=1024, F=64, H=20, C=2, ratio=0.25, p=0.01, n_min=1024, onehot=False,
-               name="S-ER: Erdos-Renyi B=256, N=1024, F=64, K=256, H=E=20, 1 pool"),
+    "er": dict(B=256, N=1024, F=64, H=20, C=2, ratio=0.25, p=0.01, n_min=1024, onehot=False, num_pooling=2, roofline="mfma",
+               name="S-ER: Erdos-Renyi B=256, N=1024, F=64, H=E=20, 2 pooling levels K=256->64 (SURVEY 8d)"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
 
 
 def make_model_and_batch(w, linkpred, device, seed_offset=0):
@@ -48,7 +49,7 @@ def make_model_and_batch(w, linkpred, device, seed_offset=0):
     x, adj, nn_, label = O.make_batch(w["B"], w["N"], w["F"], n_min=w["n_min"], p=w["p"], seed=1 + seed_offset,
                                       n_classes=w["C"], onehot=w["onehot"])
     model = SoftPoolingGcnEncoder(w["N"], w["F"], w["H"], w["H"], w["C"], 3, w["H"], assign_ratio=w["ratio"],
-                                  linkpred=linkpred)
+                                  num_pooling=w.get("num_pooling", 1), linkpred=linkpred)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     params = O.init_params(shapes, seed=0)
     model.load_state_dict(params)
@@ -69,7 +70,8 @@ def cpu_baseline(cpu, w, linkpred, budget_s=15.0):
     def step():
         for v in P.values():
             v.grad = None
-        y, inter = O.softpool_forward(P, cpu["x"], cpu["adj"], cpu["nn"], cpu["x"])
+        y, inter = O.softpool_forward(P, cpu["x"], cpu["adj"], cpu["nn"], cpu["x"],
+                                      num_pooling=w.get("num_pooling", 1))
         loss, _ = O.softpool_loss(y, cpu["label"], inter["assign_0"], cpu["adj"], cpu["nn"], linkpred)
         loss.backward()
 
@@ -151,10 +153,62 @@ def roofline_probe(w, device, iters=200):
         traffic = None
     return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                kernel=f"k_aggregate<false,{ct},16> " + ("bf16-packed A x 3-plane bf16 V (exact)" if packed
-                                                          else "fp32 panel") + " — level-0 aggregation A·[XW_e|XW_a]",
+                kernel=(f"k_aggregate_wide<{ct}>" if packed and B * ((N + 127) // 128) >= 512 else f"k_aggregate<false,{ct},16>")
+                + (" bf16-packed A x 3-plane bf16 V (exact)" if packed else " fp32 panel")
+                + " — level-0 aggregation A·[XW_e|XW_a]",
                 us_per_launch=round(us, 2), algorithmic_bytes=bytes_alg,
                 fp32_equiv={"bytes": fp32_bytes, "GB/s": round(fp32_bytes / (us * 1e-6) / 1e9, 1)})
+
+
+def mfma_probe(w, device, iters=50):
+    """The pooling pass T = A^T S (N x N by N x K, K = int(N * ratio) clusters) of S^T A S, as the encoder plan runs it
+    for 0/1 adjacency at K > 128: k_aggregate_wide_dma on the bf16-packed A^T against the exact 3-plane bf16 split
+    of S (presplit by the softmax producer).  MFMA-bound: `achieved` prices the ALGORITHMIC flops 2*N*N*K per graph
+    against the dense bf16 MFMA peak; `mfma_executed` counts the three plane products the exact split really issues
+    (K padded to the kernel's 16-column tiles)."""
+    from graph_pooling_amd import _lib
+    lib = _lib.load()
+    B, N = w["B"], w["N"]
+    K = int(N * w["ratio"])
+    A = (torch.rand(B, N, N, device=device) < w["p"]).float()
+    V = torch.softmax(torch.randn(B, N, K, device=device), -1)
+    U = torch.empty(B, N, K, device=device)
+    st = torch.cuda.current_stream()
+    nb = lib.dp_adj_pack_bytes(B, N)
+    pk = torch.empty(nb, device=device, dtype=torch.uint8)
+    pkt = torch.empty(nb, device=device, dtype=torch.uint8)
+    flag = torch.zeros(64, device=device, dtype=torch.int32)
+    _lib.check(lib.dp_adj_pack(A.data_ptr(), pk.data_ptr(), pkt.data_ptr(), flag.data_ptr(), B, N, st.cuda_stream))
+    wsb = lib.dp_adj_aggregate_packed_workspace_bytes(B, N, K)
+    ws = torch.empty(wsb, device=device, dtype=torch.uint8)
+
+    def launch(presplit):
+        _lib.check(lib.dp_adj_aggregate_packed(A.data_ptr(), pk.data_ptr(), pkt.data_ptr(), flag.data_ptr(),
+                                               V.data_ptr(), K, U.data_ptr(), K, B, N, K, 1, 0.0, presplit,
+                                               ws.data_ptr(), wsb, st.cuda_stream))
+    launch(0)
+    for _ in range(5):
+        launch(1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        launch(1)
+    e1.record(st)
+    e1.synchronize()
+    # two launches per call when K > 128 (the flag-gated fp32 fallback exits at once); its few us are included
+    us = e0.elapsed_time(e1) * 1000.0 / iters
+    alg = 2.0 * B * N * N * K
+    ct = (K + 15) // 16
+    ct = ct if ct <= 8 else (ct + 1) // 2 * 2
+    executed = 2.0 * B * N * (((N + 31) // 32) * 32) * ct * 16 * 3
+    tf = alg / (us * 1e-6) / 1e12
+    return dict(bound="mfma", achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
+                frac=round(tf / MFMA_BF16_PEAK_TF, 4), traffic=None,
+                kernel=f"k_aggregate_wide_dma<{ct},8>: T = A^T S of the pooling step, bf16-packed A^T x 3-plane bf16 S "
+                       f"(exact), B={B} N={N} K={K}",
+                us_per_launch=round(us, 2), algorithmic_flops=alg,
+                mfma_executed={"flops": executed, "TFLOP/s": round(executed / (us * 1e-6) / 1e12, 1),
+                               "frac_of_bf16_peak": round(executed / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF, 4)})
 
 
 def main():
@@ -195,7 +249,7 @@ def main():
 
     w = WORKLOADS[args.workload]
     if args.probe_only:
-        print(json.dumps({"roofline": roofline_probe(w, device)}))
+        print(json.dumps({"roofline": mfma_probe(w, device) if w.get("roofline") == "mfma" else roofline_probe(w, device)}))
         return
     model, batch, cpu = make_model_and_batch(w, args.linkpred, device, seed_offset=rank)
     dp = None
@@ -278,7 +332,12 @@ def main():
                        "parallelism": f"dp{world}"},
         }
         if world == 1:
-            out["roofline"] = roofline_probe(w, device)
+            if w.get("roofline") == "mfma":
+                # the ER workload is the MFMA-bound one: its dominant kernel is the wide pooling product
+                out["roofline"] = mfma_probe(w, device)
+                out["roofline_hbm"] = roofline_probe(w, device)
+            else:
+                out["roofline"] = roofline_probe(w, device)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cpu, w, args.linkpred)
         print(json.dumps(out))
