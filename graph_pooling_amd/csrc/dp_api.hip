@@ -1,6 +1,8 @@
 // extern "C" boundary of libdiffpool_hip.so: argument checks, then the launch sequences.
 #include <cstdarg>
 
+#include <cmath>
+
 #include "dp_common.h"
 
 namespace dp {
@@ -533,6 +535,24 @@ int dp_loss_backward(const float* prob, const long long* label, const float* S, 
     DP_CHECK_ARG(!linkpred || (S && adj && dS && N > 0 && K > 0), "linkpred needs S, adj, dS, N, K");
     Seq q(STREAM(stream), workspace, workspace_bytes);
     loss_bwd_seq(q, prob, label, S, adj, num_nodes, dloss, d_ypred, dS, B, C, N, K, linkpred);
+    return q.err;
+}
+
+size_t dp_clip_adam_workspace_bytes(void) { return 4096; }
+int dp_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, int step, float lr,
+                      float beta1, float beta2, float eps, float max_norm, float* total_norm_out, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    NOTNULL(params); NOTNULL(grads); NOTNULL(exp_avg); NOTNULL(exp_avg_sq);
+    DP_CHECK_ARG(n >= 0, "n=%ld must be >= 0", n);
+    DP_CHECK_ARG(step >= 1, "step=%d is the 1-based count of this update", step);
+    DP_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "betas (%g, %g) must lie in [0, 1)",
+                 (double)beta1, (double)beta2);
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    // bias corrections in double on the host, exactly as torch.optim.Adam's single-tensor path computes them
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    clip_adam_step(q, params, grads, exp_avg, exp_avg_sq, n, max_norm, beta1, beta2, eps, (float)((double)lr / bc1),
+                   (float)(1.0 / std::sqrt(bc2)), total_norm_out);
     return q.err;
 }
 

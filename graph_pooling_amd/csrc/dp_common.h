@@ -242,6 +242,10 @@ bool head_supported(const HeadArgs& a);
 void head_fwd(Seq& q, const HeadArgs& a);
 void head_bwd(Seq& q, const HeadBwdArgs& a);
 
+// (dp_optim.hip)
+void clip_adam_step(Seq& q, float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_norm,
+                    float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt, float* total_norm_out);
+
 // (dp_linkpred.hip)
 void linkpred_fwd(Seq& q, const float* S, int lds, const float* adj, const int* num_nodes, float* loss_out,
                   int B, int n, int K);

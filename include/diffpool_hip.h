@@ -255,6 +255,17 @@ int dp_loss_backward(const float* prob, const long long* label, const float* S, 
                      const int* num_nodes, const float* dloss, float* d_ypred, float* dS, int B, int C,
                      int N, int K, int linkpred, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ N2  fused gradient clip + Adam step
+ * train.py:209-210 on top of the Adam of train.py:173, over the flat fp32 parameter / gradient buffers (n floats):
+ *   total = ||grads||_2;  grads *= min(1, max_norm / (total + 1e-6))   (max_norm <= 0: no clipping)
+ *   exp_avg = b1 exp_avg + (1-b1) g;  exp_avg_sq = b2 exp_avg_sq + (1-b2) g^2
+ *   params -= lr / (1 - b1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - b2^step) + eps)
+ * step >= 1 is the 1-based count of this update.  total_norm_out: device float or NULL.  Two launches. */
+size_t dp_clip_adam_workspace_bytes(void);
+int dp_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, int step, float lr,
+                      float beta1, float beta2, float eps, float max_norm, float* total_norm_out, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif
