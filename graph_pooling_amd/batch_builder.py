@@ -1,0 +1,114 @@
+"""On-device batch builder.
+
+The reference assembles every batch on the host — `GraphSampler.__getitem__` pads a dense float64 adjacency per
+graph, the DataLoader stacks them, `train.py:197-201` converts to float32 and copies `[B,N,N]` to the GPU: 20 MB per
+DD step, more PCIe time than the whole fused forward + backward.  Here the dataset is held as edge lists; a batch
+is shipped as a few int32 arrays (edges, offsets, node labels) and `dp_build_batch` writes the padded dense batch
+in device memory, in the layout the encoders take (`adj [B,N,N]`, one-hot `feats [B,N,F]`, `num_nodes`).
+
+    ds = EdgeListDataset.from_tu_graphs(read_tu_graphs(datadir, "ENZYMES", max_nodes=100))
+    builder = DeviceBatchBuilder(ds, max_nodes=100, feat_dim=3, device="cuda")
+    batch = builder.build(indices)        # same keys as tu_dataset.collate / the reference's DataLoader batches
+    ypred = model(batch["feats"], batch["adj"], batch["num_nodes"], assign_x=batch["assign_feats"])
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class EdgeListDataset:
+    """Graphs as concatenated int32 edge lists (each undirected edge once, i < j) + node labels + graph labels."""
+
+    def __init__(self, edge_src, edge_dst, edge_ptr, node_label, node_ptr, graph_label):
+        self.edge_src = np.ascontiguousarray(edge_src, dtype=np.int32)
+        self.edge_dst = np.ascontiguousarray(edge_dst, dtype=np.int32)
+        self.edge_ptr = np.ascontiguousarray(edge_ptr, dtype=np.int64)
+        self.node_label = np.ascontiguousarray(node_label, dtype=np.int32)
+        self.node_ptr = np.ascontiguousarray(node_ptr, dtype=np.int64)
+        self.graph_label = np.ascontiguousarray(graph_label, dtype=np.int64)
+
+    def __len__(self):
+        return len(self.graph_label)
+
+    def num_nodes(self, g: int) -> int:
+        return int(self.node_ptr[g + 1] - self.node_ptr[g])
+
+    @classmethod
+    def from_tu_graphs(cls, graphs) -> "EdgeListDataset":
+        """From tu_dataset.TUGraph objects (dense symmetric 0/1 adjacency, optional node labels)."""
+        srcs, dsts, labels, eptr, nptr, gl = [], [], [], [0], [0], []
+        for g in graphs:
+            i, j = np.nonzero(np.triu(g.adj, 1))
+            srcs.append(i.astype(np.int32))
+            dsts.append(j.astype(np.int32))
+            eptr.append(eptr[-1] + len(i))
+            n = g.num_nodes
+            labels.append(np.asarray(g.node_label, dtype=np.int32) if g.node_label is not None
+                          else np.zeros(n, dtype=np.int32))
+            nptr.append(nptr[-1] + n)
+            gl.append(g.label)
+        cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dtype=dt)   # noqa: E731
+        return cls(cat(srcs, np.int32), cat(dsts, np.int32), eptr, cat(labels, np.int32), nptr, gl)
+
+    def gather(self, indices: Sequence[int]):
+        """Host arrays of one batch: (src, dst, edge_ptr[B+1], node_label, node_ptr[B+1], graph_label, max_edges)."""
+        idx = np.asarray(indices, dtype=np.int64)
+        e0, e1 = self.edge_ptr[idx], self.edge_ptr[idx + 1]
+        n0, n1 = self.node_ptr[idx], self.node_ptr[idx + 1]
+        src = np.concatenate([self.edge_src[a:b] for a, b in zip(e0, e1)]) if len(idx) else np.zeros(0, np.int32)
+        dst = np.concatenate([self.edge_dst[a:b] for a, b in zip(e0, e1)]) if len(idx) else np.zeros(0, np.int32)
+        lab = np.concatenate([self.node_label[a:b] for a, b in zip(n0, n1)]) if len(idx) else np.zeros(0, np.int32)
+        edge_ptr = np.concatenate([[0], np.cumsum(e1 - e0)]).astype(np.int32)
+        node_ptr = np.concatenate([[0], np.cumsum(n1 - n0)]).astype(np.int32)
+        max_edges = int((e1 - e0).max()) if len(idx) else 0
+        return src, dst, edge_ptr, lab, node_ptr, self.graph_label[idx], max_edges
+
+
+class DeviceBatchBuilder:
+    def __init__(self, dataset: EdgeListDataset, max_nodes: int, feat_dim: int, device="cuda"):
+        self.ds, self.N, self.F = dataset, int(max_nodes), int(feat_dim)
+        self.device = torch.device(device)
+
+    def build(self, indices: Sequence[int], check: bool = True) -> Dict[str, object]:
+        """Device tensors `adj`, `feats` (= `assign_feats`), `label`, plus `num_nodes` as the host int array the
+        reference passes (train.py:200) and `num_nodes_device`.  The batch is validated on the host (sizes, label
+        range) before anything is shipped; `check` additionally reads back the kernel's skipped-entry counter."""
+        lib = _lib.load()
+        src, dst, edge_ptr, lab, node_ptr, glabel, max_edges = self.ds.gather(indices)
+        B = len(glabel)
+        if B == 0:
+            raise ValueError("empty batch")
+        n = np.diff(node_ptr)
+        if int(n.max()) > self.N:
+            raise ValueError(f"a graph of the batch has {int(n.max())} nodes > max_nodes={self.N} "
+                             "(the reference's loader drops such graphs, load_data.py:79)")
+        if len(lab) and (int(lab.min()) < 0 or int(lab.max()) >= self.F):
+            raise ValueError(f"node label outside [0, {self.F})")
+        dev = self.device
+        # ONE host->device copy: all int32 arrays back to back
+        parts = [src, dst, edge_ptr, lab, node_ptr]
+        offs = np.cumsum([0] + [len(p) for p in parts])
+        host = torch.from_numpy(np.concatenate(parts).astype(np.int32))
+        if dev.type == "cuda":
+            host = host.pin_memory()
+        packed = host.to(dev, non_blocking=True)
+        view = [packed[offs[i]:offs[i + 1]] for i in range(len(parts))]
+        adj = torch.empty(B, self.N, self.N, device=dev, dtype=torch.float32)
+        feats = torch.empty(B, self.N, self.F, device=dev, dtype=torch.float32)
+        nn_dev = torch.empty(B, device=dev, dtype=torch.int32)
+        errors = torch.zeros(1, device=dev, dtype=torch.int32)
+        _lib.require_gpu_tensor(adj, "adj")
+        ptr = lambda t: t.data_ptr() if t.numel() else errors.data_ptr()          # noqa: E731  (never dereferenced)
+        _lib.check(lib.dp_build_batch(ptr(view[0]), ptr(view[1]), view[2].data_ptr(), ptr(view[3]), view[4].data_ptr(),
+                                      adj.data_ptr(), feats.data_ptr(), nn_dev.data_ptr(), errors.data_ptr(), B, self.N,
+                                      self.F, 1, max_edges, _lib.current_stream()), "dp_build_batch")
+        if check and int(errors.item()) != 0:
+            raise RuntimeError(f"dp_build_batch skipped {int(errors.item())} out-of-range entries")
+        label = torch.from_numpy(glabel).to(dev, non_blocking=True)
+        return {"adj": adj, "feats": feats, "assign_feats": feats, "label": label,
+                "num_nodes": n.astype(np.int32), "num_nodes_device": nn_dev}

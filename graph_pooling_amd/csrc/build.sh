@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libdiffpool_hip.so
-SRCS="dp_api.hip dp_gemm.hip dp_rowops.hip dp_linkpred.hip dp_model.hip dp_set2set.hip dp_meanagg.hip dp_agg.hip dp_small.hip dp_head.hip dp_optim.hip"
+SRCS="dp_api.hip dp_gemm.hip dp_rowops.hip dp_linkpred.hip dp_model.hip dp_set2set.hip dp_meanagg.hip dp_agg.hip dp_small.hip dp_head.hip dp_optim.hip dp_batch.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fvisibility=hidden"
 mkdir -p build
 pids=()

@@ -538,6 +538,19 @@ int dp_loss_backward(const float* prob, const long long* label, const float* S, 
     return q.err;
 }
 
+int dp_build_batch(const int* edge_src, const int* edge_dst, const int* edge_ptr, const int* node_label,
+                   const int* node_ptr, float* adj, float* feats, int* num_nodes, int* errors, int B, int N, int F,
+                   int symmetric, int max_edges_per_graph, void* stream) {
+    NOTNULL(edge_src); NOTNULL(edge_dst); NOTNULL(edge_ptr); NOTNULL(node_ptr); NOTNULL(adj); NOTNULL(num_nodes);
+    NOTNULL(errors);
+    NONNEG(B); NONNEG(N);
+    DP_CHECK_ARG(!feats || (node_label && F > 0), "one-hot features need node labels and F > 0");
+    Seq q(STREAM(stream), nullptr, 0);
+    build_batch(q, edge_src, edge_dst, edge_ptr, node_label, node_ptr, adj, feats, num_nodes, errors, B, N, F, symmetric,
+                max_edges_per_graph);
+    return q.err;
+}
+
 size_t dp_clip_adam_workspace_bytes(void) { return 4096; }
 int dp_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, int step, float lr,
                       float beta1, float beta2, float eps, float max_norm, float* total_norm_out, void* workspace,
