@@ -166,10 +166,13 @@ void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat /*BN output, null when n
 int rownorm_bwd_chunks(int n);
 void colsum_batched(Seq& q, const float* X, int ldx, long strideX, int rows, int cols, float* out,
                     long strideOut, int batch, int rowsplit = 1);
+// vs: also emit the 3-plane bf16 split of S (dp_agg.hip layout); zero_p/zero_bytes: also zero-fill that region
 void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, const int* num_nodes, int B,
-                      int n, int K, float* S2 = nullptr);
+                      int n, int K, float* S2 = nullptr, unsigned short* vs = nullptr, void* zero_p = nullptr,
+                      size_t zero_bytes = 0);
+// dbias: slab row of graph 0 for the column sums of dlogits (graphs dbias_stride floats apart, atomically added)
 void softmax_mask_bwd(Seq& q, const float* S, int lds, const float* dS, int ldds, const int* num_nodes,
-                      float* dlogits, int ldl, int B, int n, int K);
+                      float* dlogits, int ldl, int B, int n, int K, float* dbias = nullptr, long dbias_stride = 0);
 void masked_max_fwd(Seq& q, const float* Z, int ldz, const int* num_nodes, float* out, int ldo, int* argmax,
                     int lda, int B, int n, int F);
 void masked_max_bwd(Seq& q, const float* dout, int ldo, const int* argmax, int lda, float* dZ, int ldz, int B,

@@ -540,18 +540,20 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
             // S = softmax(Za Wp^T + bp) * mask
             bgemm(q, lv.Za, PW(params, c.assign_pred_w_off[j]), sc.logits, PW(params, c.assign_pred_b_off[j]), B, n, K,
                   li.Da, li.Da, li.Da, K, (long)n * li.Da, 0, (long)n * K, false, true, 1.f, 0.f, 0);
-            softmax_mask_fwd(q, sc.logits, K, lv.S, K, nn_j, B, n, K, j == 0 ? assign_out : nullptr);
-            // X' = S^T Z ; T = S^T A ; A' = T S
             // X' = S^T Z ;  Tt = A^T S  (= (S^T A)^T, [n x K]) ;  A' = Tt^T S.   X' and A' contract over the node
-            // index (K = n): split-K with float atomics into the zeroed outputs when the level is large
+            // index (K = n): split-K with float atomics into the zeroed outputs when the level is large.  The softmax
+            // launch also zero-fills those outputs and writes the bf16 split of S for the packed A^T S pass.
             const int ksn = n >= 256 ? node_ksplit(c) : 1;
-            if (ksn > 1) zero_fill(q, lv.Xn, align256((size_t)((char*)(lv.An + (size_t)B * K * K) - (char*)lv.Xn)));
+            const bool s_split = j == 0 && pkp && aggregate_packed_usable(io.adj, n, K);
+            softmax_mask_fwd(q, sc.logits, K, lv.S, K, nn_j, B, n, K, j == 0 ? assign_out : nullptr,
+                             s_split ? sc.vs : nullptr, ksn > 1 ? lv.Xn : nullptr,
+                             ksn > 1 ? align256((size_t)((char*)(lv.An + (size_t)B * K * K) - (char*)lv.Xn)) : 0);
             {
                 GemmDesc d{lv.S, lv.Ze, lv.Xn, nullptr, K, li.D, n, K, li.D, li.D, (long)n * K, (long)n * li.D,
                            (long)K * li.D, true, false, 1.f, 0.f, 0, 0, ksn > 1 ? 1 : 0};
                 bgemm_group(q, &d, 1, B, ksn);
             }
-            aggregate(q, io.adj, lv.S, K, lv.T, K, B, n, K, true, 0.f, j == 0 ? pkp : nullptr, sc.vs);
+            aggregate(q, io.adj, lv.S, K, lv.T, K, B, n, K, true, 0.f, j == 0 ? pkp : nullptr, sc.vs, s_split);
             {
                 GemmDesc d{lv.T, lv.S, lv.An, nullptr, K, K, n, K, K, K, (long)n * K, (long)n * K, (long)K * K, true,
                            false, 1.f, 0.f, 0, 0, ksn > 1 ? 1 : 0};
@@ -591,6 +593,9 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
         gr[j].dX0 = j >= 1 ? q.alloc<float>(rows * li.e->dims[0]) : nullptr;
         gr[j].dAdj = j >= 1 ? q.alloc<float>(rows * li.n) : nullptr;
     }
+    // ... and so are the gradient slabs (atomic bias sums; unused split-K rows), so they sit in the same block
+    const int KS = node_ksplit(c);
+    float* slabs = q.alloc<float>((size_t)B * KS * (c.n_graph_params > 0 ? c.n_graph_params : 1));
     const size_t zero_end = q.ws_off;
     for (int j = 0; j <= P; ++j) {
         const LevelInfo li = level_info(c, j);
@@ -611,8 +616,6 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     float* dlog = q.alloc<float>(maxSK ? maxSK : 1);
     float* V = q.alloc<float>(maxSK ? maxSK : 1);
     float* V2 = q.alloc<float>(maxSK ? maxSK : 1);
-    const int KS = node_ksplit(c);
-    float* slabs = q.alloc<float>((size_t)B * KS * (c.n_graph_params > 0 ? c.n_graph_params : 1));
     float* dh[DP_MAX_PRED + 2];
     for (int i = 0; i < c.n_pred; ++i) dh[i] = q.alloc<float>((size_t)B * c.pred_dims[i]);
     dh[c.n_pred] = const_cast<float*>(d_ypred);   // read only
@@ -628,9 +631,8 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
 
     // every entry of `grads` is written below (weights: slab reduce / direct GEMM; biases: reduce_bias /
     // column sums), so no memset of it is needed
+    // (one launch: level gradient accumulators + the slabs, which receive atomic adds and leave split-K rows unused)
     zero_fill(q, q.ws + zero_begin, zero_end - zero_begin);
-    // the slabs receive atomic adds (bias sums) and leave split-K rows unused: zero them once per backward
-    zero_fill(q, slabs, align256((size_t)B * KS * c.n_graph_params * sizeof(float)));
     const bool fused_head = head_usable(c);
     if (fused_head) {
         // pred_model backward + the max-readout scatter of every level in one launch
@@ -722,7 +724,8 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
                 bgemm(q, V2, lv.S, gr[j].dAdj, nullptr, B, n, n, K, K, K, n, (long)n * K, (long)n * K, (long)n * n, false,
                       true, 1.f, 1.f, 0);
             if (j == 0 && d_assign) axpy(q, dS, d_assign, 1.f, (long)B * n * K);
-            softmax_mask_bwd(q, lv.S, K, dS, K, j == 0 ? num_nodes : nullptr, dlog, K, B, n, K);
+            softmax_mask_bwd(q, lv.S, K, dS, K, j == 0 ? num_nodes : nullptr, dlog, K, B, n, K,
+                             c.assign_pred_b_off[j] >= 0 ? slabs + c.assign_pred_b_off[j] : nullptr, slab_stride * KS);
             // assign_pred: logits = Za Wp^T + bp
             {
                 const int ksn = n >= 256 ? KS : 1;
@@ -732,9 +735,6 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
                 bgemm(q, dlog, PW(params, c.assign_pred_w_off[j]), gr[j].dZa, nullptr, B, n, li.Da, K, K, li.Da, li.Da,
                       (long)n * K, 0, (long)n * li.Da, false, false, 1.f, 0.f, 0);
             }
-            if (c.assign_pred_b_off[j] >= 0)
-                colsum_batched(q, dlog, K, (long)n * K, n, K, slabs + c.assign_pred_b_off[j], slab_stride * KS, B,
-                               n >= 256 ? 8 : 1);
         }
         level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, KS, Pj, dUj, Gj, part, part_b,
                        j == 0 ? pkp : nullptr, vs);

@@ -450,10 +450,99 @@ __global__ __launch_bounds__(256) void k_softmax_mask_fwd(const float* logits, i
         }
     }
 }
+// Encoder-plan variant: grid (16-row chunks, B).  Besides S (and the caller-visible copy S2) the workgroup writes the
+// exact 3-plane bf16 split of its 16 rows of S in the layout the packed aggregation reads (two k8 groups; the last
+// chunk also writes the zero k8 groups that pad n to a multiple of 32), and the grid zero-fills `zero_p`
+// (the split-K accumulators X', A' of the pooling products) — two small launches folded into this one.
+struct SoftmaxFwdArgs {
+    const float* logits;
+    int ldl;
+    float* S;
+    int lds;
+    float* S2;
+    const int* num_nodes;
+    int n, K;
+    unsigned short* vs;
+    int vs_ct, vs_k8;
+    uint4* zero_p;
+    long zero_n16;
+};
+__global__ __launch_bounds__(256) void k_softmax_mask_fwd_plan(SoftmaxFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [16][K]
+    const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    if (a.zero_p) {
+        const long wg = (long)b * gridDim.x + chunk, nwg = (long)gridDim.x * gridDim.y;
+        for (long i = wg * 256 + threadIdx.x; i < a.zero_n16; i += nwg * 256) a.zero_p[i] = make_uint4(0, 0, 0, 0);
+    }
+    const int node = chunk * 16 + team;
+    const int K = a.K;
+    if (node < a.n) {
+        const long row = (long)b * a.n + node;
+        const bool valid = a.num_nodes ? node < a.num_nodes[b] : true;
+        const float* l = a.logits + row * a.ldl;
+        float* s = a.S + row * a.lds;
+        float* s2 = a.S2 ? a.S2 + row * a.lds : nullptr;
+        float m = -INFINITY;
+        for (int c = tl; c < K; c += 16) m = fmaxf(m, l[c]);
+        m = team_max(m);
+        float sum = 0.f;
+        for (int c = tl; c < K; c += 16) sum += expf(l[c] - m);
+        sum = team_sum(sum);
+        const float r = 1.f / sum;
+        for (int c = tl; c < K; c += 16) {
+            const float v = valid ? expf(l[c] - m) * r : 0.f;
+            s[c] = v;
+            if (s2) s2[c] = v;
+            tile[team * K + c] = v;
+        }
+    } else {
+        for (int c = tl; c < K; c += 16) tile[team * K + c] = 0.f;
+    }
+    if (!a.vs) return;
+    __syncthreads();
+    unsigned short* vb = a.vs + (long)b * 3 * a.vs_ct * a.vs_k8 * 128;
+    const long pl = (long)a.vs_ct * a.vs_k8 * 128;
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    const int kend = chunk == (int)gridDim.x - 1 ? a.vs_k8 : 2 * chunk + 2;   // last chunk: zero groups up to k8 pad
+    for (int item = threadIdx.x; item < (kend - 2 * chunk) * a.vs_ct * 16; item += 256) {
+        const int k8 = 2 * chunk + item / (a.vs_ct * 16), vc = item % (a.vs_ct * 16);
+        const int lr = (k8 - 2 * chunk) * 8;                     // first local row of this k8 group (>= 16: padding)
+        u16x8 h, m, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = (lr < 16 && vc < K) ? tile[(lr + j) * K + vc] : 0.f;
+            unsigned short hh, mm, ll;
+            bf16_split3(v, hh, mm, ll);
+            h[j] = hh; m[j] = mm; l[j] = ll;
+        }
+        const long o = vs_index(0, a.vs_ct, a.vs_k8, vc >> 4, k8, vc & 15, 0);
+        *reinterpret_cast<u16x8*>(vb + o) = h;
+        *reinterpret_cast<u16x8*>(vb + o + pl) = m;
+        *reinterpret_cast<u16x8*>(vb + o + 2 * pl) = l;
+    }
+}
 void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, const int* num_nodes, int B, int n,
-                      int K, float* S2) {
+                      int K, float* S2, unsigned short* vs, void* zero_p, size_t zero_bytes) {
     if (!q.ok()) return;
     const long rows = (long)B * n;
+    const bool fits = (size_t)16 * K * sizeof(float) <= 48 * 1024;   // (a split is only ever asked for K <= 320)
+    if (!fits && zero_p) {
+        zero_fill(q, zero_p, zero_bytes);
+        zero_p = nullptr;
+    }
+    if (fits && (vs || zero_p)) {
+        if (zero_p && ((reinterpret_cast<uintptr_t>(zero_p) & 15) != 0 || (zero_bytes & 15) != 0)) {
+            q.zero(zero_p, zero_bytes);
+            zero_p = nullptr;
+        }
+        SoftmaxFwdArgs a{logits, ldl, S, lds, S2, num_nodes, n, K, vs, (K + 15) / 16, ((n + 31) / 32) * 4,
+                         (uint4*)zero_p, (long)(zero_bytes / 16)};
+        hipLaunchKernelGGL(k_softmax_mask_fwd_plan, dim3((n + 15) / 16, B), dim3(256), (size_t)16 * K * sizeof(float),
+                           q.stream, a);
+        q.check_launch("softmax_mask_fwd_plan");
+        return;
+    }
     hipLaunchKernelGGL(k_softmax_mask_fwd, dim3(team_grid(rows)), dim3(256), 0, q.stream, logits, ldl, S, lds, S2,
                        num_nodes, rows, n, K);
     q.check_launch("softmax_mask_fwd");
@@ -476,13 +565,53 @@ __global__ __launch_bounds__(256) void k_softmax_mask_bwd(const float* S, int ld
         for (int c = tl; c < K; c += 16) o[c] = s[c] * (d[c] - dot);
     }
 }
+// Encoder-plan variant: grid (64-row chunks, B); also adds the column sums of dlogits (the assign_pred bias
+// gradient) of its rows to the graph's slab row with one float atomic per column and workgroup.
+__global__ __launch_bounds__(256) void k_softmax_mask_bwd_plan(const float* S, int lds, const float* dS, int ldds,
+                                                               float* dl, int ldl, int n, int K, float* dbias,
+                                                               long dbias_stride) {
+    extern __shared__ float colsum[];                 // [16 teams][K]
+    const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
+    const int b = blockIdx.y;
+    float* mysum = colsum + team * K;
+    for (int c = tl; c < K; c += 16) mysum[c] = 0.f;
+    const int r0 = blockIdx.x * 64, r1 = min(n, r0 + 64);
+    for (int node = r0 + team; node < r1; node += 16) {
+        const long row = (long)b * n + node;
+        const float* s = S + row * lds;
+        const float* d = dS + row * ldds;
+        float dot = 0.f;
+        for (int c = tl; c < K; c += 16) dot += s[c] * d[c];
+        dot = team_sum(dot);
+        float* o = dl + row * ldl;
+        for (int c = tl; c < K; c += 16) {
+            const float v = s[c] * (d[c] - dot);
+            o[c] = v;
+            mysum[c] += v;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < K; c += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += colsum[k * K + c];
+        atomicAdd(dbias + (long)b * dbias_stride + c, t);
+    }
+}
 void softmax_mask_bwd(Seq& q, const float* S, int lds, const float* dS, int ldds, const int* num_nodes,
-                      float* dlogits, int ldl, int B, int n, int K) {
+                      float* dlogits, int ldl, int B, int n, int K, float* dbias, long dbias_stride) {
     if (!q.ok()) return;
     const long rows = (long)B * n;
+    if (dbias && (size_t)16 * K * sizeof(float) <= 64 * 1024) {
+        hipLaunchKernelGGL(k_softmax_mask_bwd_plan, dim3((n + 63) / 64, B), dim3(256), (size_t)16 * K * sizeof(float),
+                           q.stream, S, lds, dS, ldds, dlogits, ldl, n, K, dbias, dbias_stride);
+        q.check_launch("softmax_mask_bwd_plan");
+        return;
+    }
     hipLaunchKernelGGL(k_softmax_mask_bwd, dim3(team_grid(rows)), dim3(256), 0, q.stream, S, lds, dS, ldds,
                        num_nodes, dlogits, ldl, rows, n, K);
     q.check_launch("softmax_mask_bwd");
+    if (dbias) colsum_batched(q, dlogits, ldl, (long)n * ldl, n, K, dbias, dbias_stride, B, n >= 256 ? 8 : 1);
 }
 
 // ------------------------------------------------------------------ masked max readout
