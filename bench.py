@@ -202,13 +202,20 @@ def mfma_probe(w, device, iters=50):
     ct = ct if ct <= 8 else (ct + 1) // 2 * 2
     executed = 2.0 * B * N * (((N + 31) // 32) * 32) * ct * 16 * 3
     tf = alg / (us * 1e-6) / 1e12
+    pmc = None
+    try:                           # MFMA-busy PMC of this kernel at this shape (profiles/r01b_er_pmc_summary.csv)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f).get("mfma_util", {}).get(f"k_aggregate_wide_dma_B{B}_N{N}_K{K}")
+    except Exception:              # noqa: BLE001
+        pmc = None
     return dict(bound="mfma", achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
                 frac=round(tf / MFMA_BF16_PEAK_TF, 4), traffic=None,
                 kernel=f"k_aggregate_wide_dma<{ct},8>: T = A^T S of the pooling step, bf16-packed A^T x 3-plane bf16 S "
                        f"(exact), B={B} N={N} K={K}",
                 us_per_launch=round(us, 2), algorithmic_flops=alg,
                 mfma_executed={"flops": executed, "TFLOP/s": round(executed / (us * 1e-6) / 1e12, 1),
-                               "frac_of_bf16_peak": round(executed / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF, 4)})
+                               "frac_of_bf16_peak": round(executed / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF, 4)},
+                mfma_busy_pmc=pmc)
 
 
 def main():
@@ -249,7 +256,10 @@ def main():
 
     w = WORKLOADS[args.workload]
     if args.probe_only:
-        print(json.dumps({"roofline": mfma_probe(w, device) if w.get("roofline") == "mfma" else roofline_probe(w, device)}))
+        out = {"roofline": roofline_probe(w, device)}
+        if w.get("roofline") == "mfma":
+            out = {"roofline": mfma_probe(w, device), "roofline_hbm": out["roofline"]}
+        print(json.dumps(out))
         return
     model, batch, cpu = make_model_and_batch(w, args.linkpred, device, seed_offset=rank)
     dp = None
