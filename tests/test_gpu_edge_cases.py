@@ -1,0 +1,94 @@
+"""Edge shapes of the DiffPool path on the GPU against the CPU oracle (PARITY UNPINNED by the reference for the
+configurations its train.py never builds — they are pinned against the oracle, which the golden fixtures pin for
+the default configuration): one cluster, one graph, one node per graph, no / several pred_model hidden layers,
+2- and 4-layer GCN stacks, a separate assign-feature width, weighted (non-bf16-exact) adjacency at a packed size.
+Tolerances as in test_gpu_model.py."""
+import numpy as np
+import pytest
+import torch
+
+from graph_pooling_amd.encoders import SoftPoolingGcnEncoder
+from oracle import diffpool_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+    b = b.detach().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(b)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all(), 'non-finite values in a parity check'
+    torch.testing.assert_close(a.float(), b.float(), rtol=rtol, atol=atol)
+
+
+def grads_close(model, ref_grads, rtol=2e-3, atol=2e-5):
+    named = dict(model.named_parameters())
+    assert set(named) == set(ref_grads), set(named) ^ set(ref_grads)
+    for k, p in named.items():
+        assert p.grad is not None, k
+        g = ref_grads[k]
+        scale = float(g.abs().max())
+        close(p.grad, g, rtol=rtol, atol=max(atol, 2e-4 * scale))
+
+
+def _run(B, N, F_, H, Cc, ratio, *, linkpred=False, num_layers=3, pred_hidden=(50,), assign_input_dim=-1,
+         n_min=None, n_max=None, p=0.2, weighted=False, seed=3):
+    n_min = max(1, N // 8) if n_min is None else n_min
+    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=n_min, n_max=n_max, p=p, seed=seed, n_classes=Cc)
+    if weighted:
+        g = torch.Generator().manual_seed(seed)
+        w = torch.rand(adj.shape, generator=g)
+        adj = adj * (w + w.transpose(1, 2)) * 0.5
+    assign_x = x
+    if assign_input_dim > 0:
+        g = torch.Generator().manual_seed(seed + 1)
+        assign_x = torch.randn(B, N, assign_input_dim, generator=g) * O.node_mask(N, nn_)
+    model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, num_layers, H, assign_ratio=ratio, linkpred=linkpred,
+                                  pred_hidden_dims=list(pred_hidden), assign_input_dim=assign_input_dim)
+    params = O.init_params({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=seed, bias_scale=0.1)
+    model.load_state_dict(params)
+    model = model.cuda()
+    ypred = model(x.cuda(), adj.cuda(), nn_, assign_x=assign_x.cuda())
+    loss = model.loss(ypred, label.cuda(), adj.cuda(), nn_) if linkpred else model.loss(ypred, label.cuda())
+    loss.backward()
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    yo, inter = O.softpool_forward(P, x, adj, nn_, assign_x, num_layers=num_layers, n_pred_hidden=len(pred_hidden))
+    lo, _ = O.softpool_loss(yo, label, inter["assign_0"], adj, nn_, linkpred)
+    lo.backward()
+    close(ypred, yo)
+    close(model.assign_tensor, inter["assign_0"], 1e-4, 1e-6)
+    close(loss, lo, 1e-4, 1e-6)
+    grads_close(model, {k: v.grad for k, v in P.items()})
+
+
+def test_single_cluster():
+    _run(4, 16, 3, 8, 3, 0.1, linkpred=True)            # K = int(16 * 0.1) = 1: S is the node mask itself
+
+
+def test_single_graph_batch():
+    _run(1, 40, 5, 8, 2, 0.25, linkpred=True)
+
+
+def test_every_graph_has_one_node():
+    _run(5, 12, 3, 8, 3, 0.25, linkpred=True, n_min=1, n_max=1)
+
+
+@pytest.mark.parametrize("hidden", [(), (16, 8)])
+def test_pred_model_depths(hidden):
+    _run(6, 30, 4, 8, 4, 0.2, pred_hidden=hidden)
+
+
+@pytest.mark.parametrize("L", [2, 4])
+def test_gcn_stack_depths(L):
+    _run(4, 36, 5, 8, 3, 0.25, num_layers=L, linkpred=True)
+
+
+def test_separate_assign_feature_width():
+    _run(4, 32, 6, 8, 3, 0.25, assign_input_dim=9)
+
+
+def test_weighted_adjacency_takes_the_fp32_fallback_at_a_packed_size():
+    _run(3, 160, 7, 12, 2, 0.25, weighted=True, linkpred=True, p=0.05)
+
+
+def test_wide_hidden_dims():
+    _run(2, 130, 10, 70, 3, 0.3, p=0.05)                 # C = 140 per joint layer: wide kernel + fused tail fallbacks
