@@ -43,9 +43,7 @@ struct AggArgs {
     const unsigned short* Vs;   // [B][3][vs_ct][K8][16][8]
     int vs_k8;
     int vs_ct;                  // ceil(C / 16)
-    int nchunks;                // column chunks of CT*16 (C > 128: the panel stays in LDS, chunks loop inside)
     const int* run_if;          // non-null: the launch is a fallback that runs only when *run_if != 0
-    int red_off;                // LDS offset (floats) of the cross-wave reduction area
     // plain epilogue
     float* U;            // [B, n, C] (ldu) or null
     int ldu;
@@ -79,7 +77,7 @@ __device__ inline float agg_team_sum(float v) {
 // exact-fp32 accumulate: acc += op(A)[r0.., :] · V   (any adjacency values)
 template <bool TRANS, int CT, int AGG_RT>
 __device__ __forceinline__ void accumulate_fp32(const AggArgs& a, int b, int r0, float* lds,
-                                                f32x4 (&acc)[AGG_RT / 16][CT], int chunk) {
+                                                f32x4 (&acc)[AGG_RT / 16][CT]) {
     constexpr int MI = AGG_RT / 16;
     const int n = a.n;
     const float* A = a.A + (long)b * n * n;
@@ -109,7 +107,7 @@ __device__ __forceinline__ void accumulate_fp32(const AggArgs& a, int b, int r0,
             for (int j = 0; j < 4; ++j) {
                 const float* vrow = V + (long)min(k0 + j, n - 1) * a.ldv;
 #pragma unroll
-                for (int cb = 0; cb < CT; ++cb) dst[j][cb] = vrow[min((chunk * CT + cb) * 16 + l15, a.C - 1)];
+                for (int cb = 0; cb < CT; ++cb) dst[j][cb] = vrow[min(cb * 16 + l15, a.C - 1)];
             }
         };
         auto mma = [&](int step, const float (&bf)[4][CT]) {
@@ -203,7 +201,7 @@ __device__ inline void dma16_raw(const void* src, void* lds_dst) {
 // LDS panel image: [RT][ldp] bf16, ldp = 8 (mod 128)  -> ds_read_b128 A-fragment reads are conflict-free.
 template <int CT, int AGG_RT>
 __device__ __forceinline__ void accumulate_bf16(const AggArgs& a, int b, int r0, float* ldsf,
-                                                f32x4 (&acc)[AGG_RT / 16][CT], int chunk, bool stage) {
+                                                f32x4 (&acc)[AGG_RT / 16][CT]) {
     constexpr int MI = AGG_RT / 16;
     unsigned short* lds = reinterpret_cast<unsigned short*>(ldsf);
     const int n = a.n, np = a.pk_ld;
@@ -226,7 +224,7 @@ __device__ __forceinline__ void accumulate_bf16(const AggArgs& a, int b, int r0,
 #pragma unroll
             for (int cb = 0; cb < CT; ++cb)
                 dst[p][cb] = *reinterpret_cast<const agg_s16x8*>(
-                    Vs + ((((long)p * CTt + min(chunk * CT + cb, CTt - 1)) * K8 + st * 4 + kq) * 16 + l15) * 8);
+                    Vs + ((((long)p * CTt + min(cb, CTt - 1)) * K8 + st * 4 + kq) * 16 + l15) * 8);
     };
     auto mma = [&](int step, const agg_s16x8 (&bf)[3][CT]) {
         agg_s16x8 av[MI];
@@ -246,7 +244,7 @@ __device__ __forceinline__ void accumulate_bf16(const AggArgs& a, int b, int r0,
     load_b(wave, f0);
     load_b(wave + 4, f1);
     // rows r0..r0+RT-1 of the packed operand: pieces (row i, segment s) of 512 bf16 = 1 KiB
-    if (stage) {
+    {
         const int pieces = AGG_RT * segs;
         for (int pc = wave; pc < pieces; pc += 4) {
             const int i = pc / segs, s = pc % segs;
@@ -267,8 +265,7 @@ __device__ __forceinline__ void accumulate_bf16(const AggArgs& a, int b, int r0,
     __syncthreads();
 }
 
-// MULTI: C > 128 — column chunks of CT*16 loop inside the kernel with the panel kept in LDS
-template <bool TRANS, int CT, int AGG_RT, bool MULTI>
+template <bool TRANS, int CT, int AGG_RT>
 __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     constexpr int MI = AGG_RT / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -293,19 +290,18 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
 
     const bool use_bf16 = a.pk_A != nullptr && __builtin_amdgcn_readfirstlane(*a.pk_flag) == 0;
     constexpr int CTP = CT * 16 + 1;
-    const int nchunks = MULTI ? a.nchunks : 1;
-    float* red = lds + (MULTI ? a.red_off : 0);        // [wave][RT][CTP]; overlays the panel when there is 1 chunk
+    float* red = lds;                                  // [wave][RT][CTP]; overlays the panel
     float* tile = red + 4 * AGG_RT * CTP;              // summed tile [RT][CTP]
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    {
         f32x4 acc[MI][CT];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < CT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (use_bf16)
-            accumulate_bf16<CT, AGG_RT>(a, b, r0, lds, acc, chunk, chunk == 0);
+            accumulate_bf16<CT, AGG_RT>(a, b, r0, lds, acc);
         else
-            accumulate_fp32<TRANS, CT, AGG_RT>(a, b, r0, lds, acc, chunk);
+            accumulate_fp32<TRANS, CT, AGG_RT>(a, b, r0, lds, acc);
 
         // ---------------- cross-wave reduction through LDS
 #pragma unroll
@@ -318,7 +314,7 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
         __syncthreads();
         for (int e = threadIdx.x; e < AGG_RT * CT * 16; e += 256) {
             const int r = e / (CT * 16), c = e % (CT * 16);
-            const int cg = chunk * CT * 16 + c;            // column in the full operand
+            const int cg = c;
             const float s = red[(0 * AGG_RT + r) * CTP + c] + red[(1 * AGG_RT + r) * CTP + c] +
                             red[(2 * AGG_RT + r) * CTP + c] + red[(3 * AGG_RT + r) * CTP + c];
             if (a.U) {
@@ -340,7 +336,6 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
                 tile[r * CTP + c] = u;
             }
         }
-        if (MULTI) __syncthreads();                        // red is rewritten by the next chunk
     }
     if (a.U) return;
     __syncthreads();
@@ -814,8 +809,7 @@ static void dispatch_wide(Seq& q, const AggArgs& a, int B) {
     }
 }
 
-static int agg_ct(int C) { return C <= 128 ? (C + 15) / 16 : 8; }
-static int agg_chunks(int C) { return C <= 128 ? 1 : (C + 127) / 128; }
+static int agg_ct(int C) { return (C + 15) / 16; }
 static size_t agg_panel_floats(bool trans, int n, int RT) {
     const int kpanel = trans ? n : (n < AGG_KP ? n : AGG_KP);
     const int segs = (kpanel + 255) / 256;
@@ -823,68 +817,60 @@ static size_t agg_panel_floats(bool trans, int n, int RT) {
     const size_t pk = ((size_t)RT * (((n + 511) / 512) * 512 + 8) * 2 + 3) / 4;     // bf16 panel, in floats
     return ((panel > pk ? panel : pk) + 3) & ~size_t(3);
 }
-static size_t agg_lds_bytes(bool trans, int n, int CT, int RT, int nchunks) {
+static size_t agg_lds_bytes(bool trans, int n, int CT, int RT) {
     const size_t panel = agg_panel_floats(trans, n, RT);
     const size_t red = (size_t)5 * RT * (CT * 16 + 1);
-    // one chunk: the reduction area overlays the panel; several: it sits behind it (the panel must survive)
-    return (nchunks > 1 ? panel + red : (panel > red ? panel : red)) * sizeof(float);
+    return (panel > red ? panel : red) * sizeof(float);    // the reduction area overlays the panel
 }
 // 16-row tiles when 32-row tiles would leave the chip with < 2 workgroups per CU (small batches): twice the
 // workgroups, four co-resident per CU, so one workgroup's panel burst overlaps its neighbours' multiplies.
 static int agg_row_tile(int B, int n, int C, bool trans) {
-    if (agg_lds_bytes(trans, n, agg_ct(C), 32, agg_chunks(C)) > 160 * 1024) return 16;   // 32 rows do not fit
+    if (agg_lds_bytes(trans, n, agg_ct(C), 32) > 160 * 1024) return 16;   // 32 rows do not fit
     return ((long)((n + 31) / 32) * B >= 512) ? 32 : 16;
 }
 
 bool aggregate_supported(const float* A, int n, int C, bool trans) {
-    // C > 128 stays on the tiled GEMM: a 16/32-row panel re-reads the whole V operand per row tile, which for
-    // wide V (ER: K = 256 clusters) is 25 GB of L2 traffic per pass — measured slower than the fp32 GEMM.  (The
-    // kernel's column-chunk loop handles such shapes correctly; it is kept for a future wide-tile variant.)
+    // C > 128 is not a panel shape: a 16/32-row panel re-reads the whole V operand per row tile (25 GB of L2
+    // traffic per pass at the ER shape).  Wide operands go to k_aggregate_wide_dma when the adjacency is packed and
+    // bf16-exact, to the tiled fp32 GEMM otherwise.
     if (n < 4 || n % 4 != 0 || C < 1 || C > 128) return false;
     if ((reinterpret_cast<uintptr_t>(A) & 15) != 0) return false;
-    return agg_lds_bytes(trans, n, agg_ct(C), 16, agg_chunks(C)) <= 160 * 1024;
+    return agg_lds_bytes(trans, n, agg_ct(C), 16) <= 160 * 1024;
 }
 
-template <bool TRANS, int CT, int RT, bool MULTI>
+template <bool TRANS, int CT, int RT>
 static void launch_agg_rt(Seq& q, const AggArgs& a, int B) {
-    const int nchunks = agg_chunks(a.C);
-    const size_t lds = agg_lds_bytes(TRANS, a.n, CT, RT, nchunks);
+    const size_t lds = agg_lds_bytes(TRANS, a.n, CT, RT);
     static bool attr_done = false;   // per instantiation: allow > 64 KiB of dynamic LDS
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate<TRANS, CT, RT, MULTI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate<TRANS, CT, RT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     AggArgs aa = a;
     aa.tiles = (a.n + RT - 1) / RT;
-    aa.nchunks = nchunks;
-    aa.red_off = nchunks > 1 ? (int)agg_panel_floats(TRANS, a.n, RT) : 0;
     aa.vs_ct = (a.C + 15) / 16;
     static const int dbg = getenv("DP_AGG_DEBUG") ? atoi(getenv("DP_AGG_DEBUG")) : 0;
     aa.dbg = dbg;
-    hipLaunchKernelGGL((k_aggregate<TRANS, CT, RT, MULTI>), dim3(aa.tiles * B), dim3(256), lds, q.stream, aa);
+    hipLaunchKernelGGL((k_aggregate<TRANS, CT, RT>), dim3(aa.tiles * B), dim3(256), lds, q.stream, aa);
 }
-template <bool TRANS, int CT, bool MULTI>
+template <bool TRANS, int CT>
 static void launch_agg(Seq& q, const AggArgs& a, int B) {
-    if (agg_row_tile(B, a.n, a.C, TRANS) == 32) launch_agg_rt<TRANS, CT, 32, MULTI>(q, a, B);
-    else launch_agg_rt<TRANS, CT, 16, MULTI>(q, a, B);
+    if (agg_row_tile(B, a.n, a.C, TRANS) == 32) launch_agg_rt<TRANS, CT, 32>(q, a, B);
+    else launch_agg_rt<TRANS, CT, 16>(q, a, B);
 }
 
 template <bool TRANS>
 static void dispatch_ct(Seq& q, const AggArgs& a, int B) {
-    if (agg_chunks(a.C) > 1) {
-        launch_agg<TRANS, 8, true>(q, a, B);
-        return;
-    }
     switch (agg_ct(a.C)) {
-        case 1: launch_agg<TRANS, 1, false>(q, a, B); break;
-        case 2: launch_agg<TRANS, 2, false>(q, a, B); break;
-        case 3: launch_agg<TRANS, 3, false>(q, a, B); break;
-        case 4: launch_agg<TRANS, 4, false>(q, a, B); break;
-        case 5: launch_agg<TRANS, 5, false>(q, a, B); break;
-        case 6: launch_agg<TRANS, 6, false>(q, a, B); break;
-        case 7: launch_agg<TRANS, 7, false>(q, a, B); break;
-        default: launch_agg<TRANS, 8, false>(q, a, B); break;
+        case 1: launch_agg<TRANS, 1>(q, a, B); break;
+        case 2: launch_agg<TRANS, 2>(q, a, B); break;
+        case 3: launch_agg<TRANS, 3>(q, a, B); break;
+        case 4: launch_agg<TRANS, 4>(q, a, B); break;
+        case 5: launch_agg<TRANS, 5>(q, a, B); break;
+        case 6: launch_agg<TRANS, 6>(q, a, B); break;
+        case 7: launch_agg<TRANS, 7>(q, a, B); break;
+        default: launch_agg<TRANS, 8>(q, a, B); break;
     }
 }
 
@@ -1041,7 +1027,7 @@ bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, cons
                            RowGroups g, GroupPtrs yout, float* invn, float* part, int B, int n, int normalize,
                            int stats_mode, const PackedAdj* pk, unsigned short* vs, bool vs_ready) {
     const int C = g.c0[g.G - 1] + g.w[g.G - 1];
-    if (!aggregate_supported(A, n, C, false) || agg_chunks(C) > 1) return false;   // the tail needs whole rows
+    if (!aggregate_supported(A, n, C, false)) return false;
     if (!q.ok()) return true;
     AggArgs a{};
     a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = nullptr;

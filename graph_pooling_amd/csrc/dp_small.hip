@@ -37,12 +37,17 @@ __device__ inline void lds_mma(const float* A, int lda, const float* B, int ldb,
     for (int t = wave; t < tm * tn; t += nwaves) {
         const int i = (t / tn) * 16 + l15, j = (t % tn) * 16 + l15;
         sm_f32x4 acc = (sm_f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+        // unconditional LDS reads on clamped indices + a select: a branch around each read makes the compiler wait
+        // for every one of them in turn (one wave per SIMD per tile here: nothing else hides that latency)
+        const int ic = min(i, M - 1), jc = min(j, N - 1);
+        const bool iok = i < M, jok = j < N;
+#pragma unroll 8
         for (int k0 = 0; k0 < K; k0 += 4) {
-            const int k = k0 + kq;
-            const bool kok = k < K;
-            const float av = (kok && i < M) ? (TA ? A[k * lda + i] : A[i * lda + k]) : 0.f;
-            const float bv = (kok && j < N) ? (TB ? B[j * ldb + k] : B[k * ldb + j]) : 0.f;
+            const int k = k0 + kq, kc = min(k, K - 1);
+            const float ar = TA ? A[kc * lda + ic] : A[ic * lda + kc];
+            const float br = TB ? B[jc * ldb + kc] : B[kc * ldb + jc];
+            const float av = (k < K && iok) ? ar : 0.f;
+            const float bv = (k < K && jok) ? br : 0.f;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
         }
 #pragma unroll
