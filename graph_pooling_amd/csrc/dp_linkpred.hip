@@ -149,7 +149,10 @@ __device__ inline float lk_dldp(float av, float raw) {
 template <int KT, int NJ>
 __global__ __launch_bounds__(256) void k_link_bwd(const float* S, int lds_ld, const float* adj, const int* num_nodes,
                                                   const float* scale_ptr, float* dS, int ldds, int n, int K,
-                                                  int accumulate) {
+                                                  int accumulate, float* part, int split_tiles) {
+    // part != null: blockIdx.z walks only `split_tiles` column tiles and stores its partial row block to
+    // part[z][b][row][K]; k_link_reduce sums the splits in a fixed order (small batches: 160 workgroups walking 8
+    // tiles each left most of the chip idle)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CW = 32 * NJ, KW = KT * 16, KP = KW + 2;
     constexpr int SA = CW + 4;      // E / A tile row stride: 4 SA = 16 mod 32, so (4 kq + r) rows x 16 cols spread over banks
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(256) void k_link_bwd(const float* S, int lds_ld, co
     const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, kq = lane >> 4;
     float* dSb = dS + (long)b * n * ldds;
     if (r0 >= nb) {                                   // rows outside the graph: gradient is zero
+        if (part) return;                             // (the reduce pass writes those zeros)
         if (!accumulate)
             for (int e = threadIdx.x; e < 64 * KW; e += 256) {
                 const int i = e / KW, k = e % KW;
@@ -193,14 +197,16 @@ __global__ __launch_bounds__(256) void k_link_bwd(const float* S, int lds_ld, co
             at[m] = Ab[(long)min(c0 + (e >> 6), n - 1) * n + min(r0 + (e & 63), n - 1)];
         }
     };
-    fetch(0);
+    const int cbeg = part ? (int)blockIdx.z * split_tiles * CW : 0;
+    const int cend = part ? min(nb, cbeg + split_tiles * CW) : nb;
+    fetch(min(cbeg, max(nb - 1, 0)));
     lk_stage<KT, 64>(Sb, lds_ld, r0, n, K, Sr);
     // this wave's share of the output block: rows wave*16.., all KT column tiles
     lk_f32x4 out[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) out[t] = (lk_f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int c0 = 0; c0 < nb; c0 += CW) {
+    for (int c0 = cbeg; c0 < cend; c0 += CW) {
         __syncthreads();                              // previous iteration's readers of Sc / Ar / At are done
 #pragma unroll
         for (int m = 0; m < NS; ++m) {
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256) void k_link_bwd(const float* S, int lds_ld, co
             At[(e >> 6) * ST + (e & 63)] = at[m];
         }
         __syncthreads();
-        if (c0 + CW < nb) fetch(c0 + CW);
+        if (c0 + CW < cend) fetch(c0 + CW);
         lk_f32x4 acc[2][NJ];
         lk_ptile<KT, NJ>(Sr, Sc, K, wr, wc, l15, kq, acc);
 #pragma unroll
@@ -248,10 +254,31 @@ __global__ __launch_bounds__(256) void k_link_bwd(const float* S, int lds_ld, co
         for (int r = 0; r < 4; ++r) {
             const int row = r0 + wave * 16 + kq * 4 + r;
             if (row < n) {
-                float* p = dSb + (long)row * ldds + col;
-                *p = accumulate ? *p + out[t][r] : out[t][r];
+                if (part) {
+                    part[(((long)blockIdx.z * gridDim.y + b) * n + row) * K + col] = out[t][r];
+                } else {
+                    float* p = dSb + (long)row * ldds + col;
+                    *p = accumulate ? *p + out[t][r] : out[t][r];
+                }
             }
         }
+    }
+}
+
+// dS[b, row, :] = (accumulate ? dS : 0) + sum_z part[z][b][row][:]   (rows >= n_b: the sum is empty)
+__global__ __launch_bounds__(256) void k_link_reduce(const float* part, int splits, const int* num_nodes, float* dS,
+                                                     int ldds, int B, int n, int K, int accumulate) {
+    const long total = (long)B * n * K;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int k = (int)(e % K);
+        const long row = e / K;
+        const int b = (int)(row / n), r = (int)(row % n);
+        const int nb = num_nodes ? min(num_nodes[b], n) : n;
+        float v = 0.f;
+        if ((r / 64) * 64 < nb)                       // the row block ran: every split stored its partial
+            for (int z = 0; z < splits; ++z) v += part[(long)z * total + e];
+        float* p = dS + row * ldds + k;
+        *p = accumulate ? *p + v : v;
     }
 }
 
@@ -304,23 +331,33 @@ void linkpred_fwd(Seq& q, const float* S, int lds_ld, const float* adj, const in
 
 template <int KT, int NJ>
 static void launch_link_bwd(Seq& q, const float* S, int lds_ld, const float* adj, const int* num_nodes,
-                            const float* scale, float* dS, int ldds, int B, int n, int K, int accumulate) {
+                            const float* scale, float* dS, int ldds, int B, int n, int K, int accumulate, float* part,
+                            int splits, int split_tiles) {
     constexpr int CW = 32 * NJ, KP = KT * 16 + 2;
     constexpr size_t bytes = ((size_t)(64 + CW) * KP + 64 * (CW + 4) + CW * 65) * sizeof(float);
     static_assert(bytes <= 160 * 1024, "link_bwd LDS");
     static bool attr = false;
     if (!attr && bytes > 64 * 1024) lk_set_lds(&k_link_bwd<KT, NJ>, bytes);
     attr = true;
-    hipLaunchKernelGGL((k_link_bwd<KT, NJ>), dim3((n + 63) / 64, B), dim3(256), bytes, q.stream, S, lds_ld, adj,
-                       num_nodes, scale, dS, ldds, n, K, accumulate);
+    hipLaunchKernelGGL((k_link_bwd<KT, NJ>), dim3((n + 63) / 64, B, part ? splits : 1), dim3(256), bytes, q.stream, S,
+                       lds_ld, adj, num_nodes, scale, dS, ldds, n, K, accumulate, part, split_tiles);
 }
 
 void linkpred_bwd(Seq& q, const float* S, int lds_ld, const float* adj, const int* num_nodes, const float* dloss,
                   float* dS, int ldds, int B, int n, int K, int accumulate) {
     if (q.err) return;
     float* scale = q.alloc<float>(64);
-    if (!q.ok()) return;
     const int kt = lk_kt(K);
+    // small batches: split the column tiles over extra workgroups (>= ~512 in all) and sum the partials afterwards
+    const int cw = kt >= 12 ? 32 : 64;
+    const int col_tiles = (n + cw - 1) / cw;
+    const long base_wgs = (long)((n + 63) / 64) * B;
+    int splits = (int)((512 + base_wgs - 1) / base_wgs);
+    splits = splits < 1 ? 1 : (splits > col_tiles ? col_tiles : splits);
+    const int split_tiles = (col_tiles + splits - 1) / splits;
+    splits = (col_tiles + split_tiles - 1) / split_tiles;
+    float* part = splits > 1 ? q.alloc<float>((size_t)splits * B * n * K) : nullptr;
+    if (!q.ok()) return;
     if (!kt) {
         set_error("linkpred backward: K=%d clusters exceed the fused tile kernel (max 256)", K);
         q.err = DP_ERR_UNSUPPORTED;
@@ -329,11 +366,22 @@ void linkpred_bwd(Seq& q, const float* S, int lds_ld, const float* adj, const in
     hipLaunchKernelGGL(k_link_final, dim3(1), dim3(256), 0, q.stream, (const float*)nullptr, 0, num_nodes, B, n,
                        (float*)nullptr, scale, dloss);
     q.check_launch("link_scale");
-#define LK_BWD(T, J) \
-    case T: launch_link_bwd<T, J>(q, S, lds_ld, adj, num_nodes, scale, dS, ldds, B, n, K, accumulate); break;
+#define LK_BWD(T, J)                                                                                             \
+    case T:                                                                                                      \
+        launch_link_bwd<T, J>(q, S, lds_ld, adj, num_nodes, scale, dS, ldds, B, n, K, accumulate, part, splits,  \
+                              split_tiles);                                                                      \
+        break;
     switch (kt) { LK_BWD(1, 2) LK_BWD(2, 2) LK_BWD(3, 2) LK_BWD(4, 2) LK_BWD(6, 2) LK_BWD(8, 2) LK_BWD(12, 1) LK_BWD(16, 1) }
 #undef LK_BWD
     q.check_launch("link_bwd");
+    if (part) {
+        const long total = (long)B * n * K;
+        long blocks = (total + 255) / 256;
+        blocks = blocks > 2048 ? 2048 : blocks;
+        hipLaunchKernelGGL(k_link_reduce, dim3((int)blocks), dim3(256), 0, q.stream, part, splits, num_nodes, dS, ldds, B,
+                           n, K, accumulate);
+        q.check_launch("link_reduce");
+    }
 }
 
 }  // namespace dp

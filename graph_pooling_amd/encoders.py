@@ -407,6 +407,13 @@ class GcnEncoderGraph(nn.Module):
             raise ValueError(f"x has {x.shape[2]} features, the encoder was built for {self.input_dim}")
         return self._run(x, adj, batch_num_nodes)
 
+    @torch.no_grad()
+    def predict(self, x, adj, batch_num_nodes=None, **kwargs):
+        """The reference's evaluate() inner loop (train.py:42-44: forward, `torch.max(ypred, 1)`, `.cpu()`), kept on
+        the device: forward under no_grad (activations go to one reusable buffer, nothing is kept for backward)
+        and the arg-max as an int64 [B] device tensor — the caller moves B integers, not B x C logits."""
+        return self.forward(x, adj, batch_num_nodes, **kwargs).argmax(dim=1)
+
     def loss(self, pred, label, type='softmax'):
         if type == 'softmax':
             return _loss(self, pred, label, None, None, None, False)

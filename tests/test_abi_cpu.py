@@ -86,8 +86,10 @@ def test_argument_errors_are_reported_before_any_launch(lib):
 
 def test_workspace_queries_run_without_gpu(lib):
     assert lib.dp_gcn_layer_workspace_bytes(4, 16, 3, 8) > 0
-    # the link loss is tile-fused: its workspace is per-tile partials, never a [B,N,N] temporary
-    assert 0 < lib.dp_linkpred_workspace_bytes(20, 500, 50) < 20 * 500 * 500 * 4 // 100
+    # the link loss is tile-fused: its workspace is per-tile loss partials and [splits,B,N,K] gradient partials,
+    # never a [B,N,N] temporary
+    assert 0 < lib.dp_linkpred_workspace_bytes(20, 500, 50) < 20 * 500 * 500 * 4 // 2
+    assert lib.dp_linkpred_workspace_bytes(256, 1024, 256) < 1 << 20          # big batches need no split
     assert lib.dp_bn_node_workspace_bytes(4, 16, 8) > 0
 
 

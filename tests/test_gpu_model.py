@@ -195,6 +195,9 @@ def test_eval_mode_and_no_grad_match_train_forward():
     with torch.no_grad():
         y2 = model(x.cuda(), adj.cuda(), nn_, assign_x=x.cuda())
     close(y1, y2, 0, 0)
+    labels = model.predict(x.cuda(), adj.cuda(), nn_, assign_x=x.cuda())
+    assert labels.dtype == torch.int64 and labels.is_cuda and labels.shape == (B,)
+    assert torch.equal(labels, y1.argmax(dim=1))
 
 
 def test_linearity_of_pooling_at_full_size():
