@@ -47,6 +47,20 @@ class DataParallelEncoder:
         m._ensure_flat(next(m.parameters()).device)
         dist.broadcast(m._flat, src=src, group=self.group)
 
+    def _average(self, flat):
+        """Mean over ranks in place: ONE collective.  RCCL averages inside the all-reduce (ncclAvg); gloo (CPU tests)
+        has no AVG, so sum and scale."""
+        if getattr(self, "_use_avg", None) is None:
+            self._use_avg = dist.get_backend(self.group) == "nccl"
+        if self._use_avg:
+            try:
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+                return
+            except (RuntimeError, ValueError):      # a collective library without ncclAvg: sum and scale instead
+                self._use_avg = False
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.div_(self.world)
+
     def _aliased_flat_grad(self):
         m = self.model
         g = getattr(m, "_last_flat_grad", None)
@@ -66,16 +80,14 @@ class DataParallelEncoder:
         flat = self._aliased_flat_grad()
         if flat is not None:
             # the autograd engine kept our views: p.grad already aliases the flat buffer
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.div_(self.world)
+            self._average(flat)
             return
         device = m._flat.device
         flat = torch.zeros(m._flat.numel(), device=device, dtype=torch.float32)
         for p, (off, numel, _) in zip(m._flat_params, m._flat_index):
             if p.grad is not None:
                 flat[off:off + numel].copy_(p.grad.reshape(-1))
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.div_(self.world)
+        self._average(flat)
         for p, (off, numel, shape) in zip(m._flat_params, m._flat_index):
             if p.grad is None:
                 p.grad = flat[off:off + numel].view(shape)
