@@ -43,19 +43,37 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
 
 
+def synthetic_batch(w, seed):
+    """Seeded synthetic padded batch in the layout graph_sampler.py:97-109 delivers: symmetric 0/1
+    zero-diagonal Erdos-Renyi adjacency in the top-left n_b x n_b block, one-hot (or N(0,1)) node features with zero
+    rows for n >= n_b, n_b ~ U{n_min..N}, uniform graph labels."""
+    g = torch.Generator().manual_seed(seed)
+    B, N, F_ = w["B"], w["N"], w["F"]
+    sizes = torch.randint(w["n_min"], N + 1, (B,), generator=g)
+    adj = torch.zeros(B, N, N)
+    x = torch.zeros(B, N, F_)
+    for b in range(B):
+        n = int(sizes[b])
+        upper = torch.triu((torch.rand(n, n, generator=g) < w["p"]).float(), diagonal=1)
+        adj[b, :n, :n] = upper + upper.t()
+        if w["onehot"]:
+            x[b, torch.arange(n), torch.randint(0, F_, (n,), generator=g)] = 1.0
+        else:
+            x[b, :n] = torch.randn(n, F_, generator=g)
+    label = torch.randint(0, w["C"], (B,), generator=g)
+    return x, adj, sizes.to(torch.int32), label
+
+
 def make_model_and_batch(w, linkpred, device, seed_offset=0):
     from graph_pooling_amd.encoders import SoftPoolingGcnEncoder
-    from oracle import diffpool_oracle as O          # synthetic batch generator + reference-style init only
-    x, adj, nn_, label = O.make_batch(w["B"], w["N"], w["F"], n_min=w["n_min"], p=w["p"], seed=1 + seed_offset,
-                                      n_classes=w["C"], onehot=w["onehot"])
+    x, adj, nn_, label = synthetic_batch(w, seed=1 + seed_offset)
+    torch.manual_seed(0)             # reference init (encoders.py:1225-1229: xavier GraphConv, default nn.Linear)
     model = SoftPoolingGcnEncoder(w["N"], w["F"], w["H"], w["H"], w["C"], 3, w["H"], assign_ratio=w["ratio"],
                                   num_pooling=w.get("num_pooling", 1), linkpred=linkpred)
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    params = O.init_params(shapes, seed=0)
-    model.load_state_dict(params)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(device)
-    batch = dict(x=x.to(device), adj=adj.to(device), nn=torch.from_numpy(nn_).to(device), label=label.to(device))
-    cpu = dict(x=x, adj=adj, nn=nn_, label=label, params=params)
+    batch = dict(x=x.to(device), adj=adj.to(device), nn=nn_.to(device), label=label.to(device))
+    cpu = dict(x=x, adj=adj, nn=nn_.numpy(), label=label, params=params)
     return model, batch, cpu
 
 
