@@ -109,6 +109,7 @@ struct GemmDesc {
     // directly instead of a separate split pass.  Rows M..8*split_k8-1 are written as zeros.
     unsigned short* split_out;
     int split_ct, split_k8, split_c0;   // total column blocks, k8 groups, column offset of this problem in V
+    int nosplit;   // this problem walks its whole K in one workgroup even when the launch is split-K (grouped siblings)
 };
 
 // hi/mid/lo bf16 planes with hi + mid + lo == v exactly (round-to-nearest-even at each step)
@@ -172,7 +173,8 @@ void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, c
                       size_t zero_bytes = 0);
 // dbias: slab row of graph 0 for the column sums of dlogits (graphs dbias_stride floats apart, atomically added)
 void softmax_mask_bwd(Seq& q, const float* S, int lds, const float* dS, int ldds, const int* num_nodes,
-                      float* dlogits, int ldl, int B, int n, int K, float* dbias = nullptr, long dbias_stride = 0);
+                      float* dlogits, int ldl, int B, int n, int K, float* dbias = nullptr, long dbias_stride = 0,
+                      const float* dS2 = nullptr /*second addend of dS, same leading dimension*/);
 void masked_max_fwd(Seq& q, const float* Z, int ldz, const int* num_nodes, float* out, int ldo, int* argmax,
                     int lda, int B, int n, int F);
 void masked_max_bwd(Seq& q, const float* dout, int ldo, const int* argmax, int lda, float* dZ, int ldz, int B,

@@ -39,7 +39,8 @@ struct GemmArgs {
     int tilesN;
     int vecA, vecB;   // operand may be read with 16-byte loads
     int tA, tB;
-    int ksplit;       // K is cut into `ksplit` ranges handled by different workgroups (blockIdx.y = b*ksplit + ks)
+    int ksplit;       // K is cut into `ksplit` ranges handled by different workgroups
+    int gsplit;       // ranges of the LAUNCH (blockIdx.y = b*gsplit + ks); a problem with ksplit < gsplit idles ks >= ksplit
     long sK;          // != 0: range ks stores its partial at C + ks*sK (slab rows, summed by the caller's reduce)
     int atomic;       // 1: ranges add into C with float atomics (C pre-zeroed / accumulated into; no bias/act)
     unsigned short* split_out;            // optional 3-plane bf16 copy of C (see GemmDesc)
@@ -145,7 +146,8 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
     float* Bs = lds + ((LA::SIZE + 3) & ~3);
 
     const int tm = tile / a.tilesN, tn = tile % a.tilesN;
-    const int b = blockIdx.y / a.ksplit, ks = blockIdx.y % a.ksplit;
+    const int b = blockIdx.y / a.gsplit, ks = blockIdx.y % a.gsplit;
+    if (ks >= a.ksplit) return;
     const float* A = a.A + (long)b * a.sA;
     const float* B = a.B + (long)b * a.sB;
     float* C = a.C + (long)b * a.sC + (long)ks * a.sK;
@@ -308,7 +310,7 @@ static void launch_tile(Seq& q, GemmGroupArgs& g, int batch) {
         total += ((mrows + BM - 1) / BM) * a.tilesN;
     }
     g.tile0[g.count] = total;
-    hipLaunchKernelGGL((bgemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(total, batch * g.p[0].ksplit), dim3(256), 0,
+    hipLaunchKernelGGL((bgemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(total, batch * g.p[0].gsplit), dim3(256), 0,
                        q.stream, g);
 }
 
@@ -330,7 +332,7 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
         if (s.M <= 0 || s.N <= 0) continue;
         GemmArgs& a = g.p[g.count++];
         a = GemmArgs{s.A, s.B, s.C, s.bias, s.M, s.N, s.K, s.lda, s.ldb, s.ldc, s.sA, s.sB, s.sC, s.alpha, s.beta,
-                     s.act, 0, 0, 0, s.tA ? 1 : 0, s.tB ? 1 : 0, ksplit, s.sK, s.atomic,
+                     s.act, 0, 0, 0, s.tA ? 1 : 0, s.tB ? 1 : 0, s.nosplit ? 1 : ksplit, ksplit, s.sK, s.atomic,
                      s.split_out, s.split_ct, s.split_k8, s.split_c0};
         a.vecA = aligned16(s.A) && (s.lda % 4 == 0) && (s.sA % 4 == 0);
         a.vecB = aligned16(s.B) && (s.ldb % 4 == 0) && (s.sB % 4 == 0);

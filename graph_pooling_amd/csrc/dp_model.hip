@@ -548,16 +548,16 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
             softmax_mask_fwd(q, sc.logits, K, lv.S, K, nn_j, B, n, K, j == 0 ? assign_out : nullptr,
                              s_split ? sc.vs : nullptr, ksn > 1 ? lv.Xn : nullptr,
                              ksn > 1 ? align256((size_t)((char*)(lv.An + (size_t)B * K * K) - (char*)lv.Xn)) : 0);
-            {
-                GemmDesc d{lv.S, lv.Ze, lv.Xn, nullptr, K, li.D, n, K, li.D, li.D, (long)n * K, (long)n * li.D,
-                           (long)K * li.D, true, false, 1.f, 0.f, 0, 0, ksn > 1 ? 1 : 0};
-                bgemm_group(q, &d, 1, B, ksn);
-            }
             aggregate(q, io.adj, lv.S, K, lv.T, K, B, n, K, true, 0.f, j == 0 ? pkp : nullptr, sc.vs, s_split);
             {
-                GemmDesc d{lv.T, lv.S, lv.An, nullptr, K, K, n, K, K, K, (long)n * K, (long)n * K, (long)K * K, true,
-                           false, 1.f, 0.f, 0, 0, ksn > 1 ? 1 : 0};
-                bgemm_group(q, &d, 1, B, ksn);
+                // both pooled outputs in ONE launch (X' does not need T, but a launch of its own costs more than
+                // waiting for the adjacency pass)
+                GemmDesc d[2] = {
+                    {lv.S, lv.Ze, lv.Xn, nullptr, K, li.D, n, K, li.D, li.D, (long)n * K, (long)n * li.D, (long)K * li.D,
+                     true, false, 1.f, 0.f, 0, 0, ksn > 1 ? 1 : 0},
+                    {lv.T, lv.S, lv.An, nullptr, K, K, n, K, K, K, (long)n * K, (long)n * K, (long)K * K, true, false, 1.f,
+                     0.f, 0, 0, ksn > 1 ? 1 : 0}};
+                bgemm_group(q, d, 2, B, ksn);
             }
         }
     }
@@ -698,6 +698,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
         if (j < P) {
             const int K = li.K, D = li.D;
             bool vsplit_used = false;
+            const float* dS2 = nullptr;
             const float* dXn = gr[j + 1].dX0;
             const float* dAn = gr[j + 1].dAdj;
             {
@@ -714,26 +715,38 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
                      0, 0, 0, vsplit, (K + 15) / 16, ((n + 31) / 32) * 4, 0},
                     {lv.S, dAn, V2, nullptr, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, false, 1.f,
                      0.f, 0}};
-                bgemm_group(q, d, gr[j].dAdj ? 4 : 3, B);
+                if (!gr[j].dAdj) {
+                    // no dA_j wanted (level 0): the fourth slot carries T dA' instead, into the idle V2 buffer; the
+                    // softmax backward adds it to dS (one launch less on the critical path)
+                    d[3] = GemmDesc{lv.T, dAn, V2, nullptr, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false,
+                                    false, 1.f, 0.f, 0};
+                    dS2 = V2;
+                }
+                bgemm_group(q, d, 4, B);
             }
-            // dS += T^T dA' ;  dS += A V
-            bgemm(q, lv.T, dAn, dS, nullptr, B, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, false, 1.f,
-                  1.f, 0);
+            // dS += T dA' ;  dS += A V
+            if (gr[j].dAdj)
+                bgemm(q, lv.T, dAn, dS, nullptr, B, n, K, K, K, K, K, (long)n * K, (long)K * K, (long)n * K, false, false,
+                      1.f, 1.f, 0);
             aggregate(q, io.adj, V, K, dS, K, B, n, K, false, 1.f, j == 0 ? pkp : nullptr, vs, vsplit_used);
             if (gr[j].dAdj)   // dA_j += (S dA') S^T
                 bgemm(q, V2, lv.S, gr[j].dAdj, nullptr, B, n, n, K, K, K, n, (long)n * K, (long)n * K, (long)n * n, false,
                       true, 1.f, 1.f, 0);
             if (j == 0 && d_assign) axpy(q, dS, d_assign, 1.f, (long)B * n * K);
             softmax_mask_bwd(q, lv.S, K, dS, K, j == 0 ? num_nodes : nullptr, dlog, K, B, n, K,
-                             c.assign_pred_b_off[j] >= 0 ? slabs + c.assign_pred_b_off[j] : nullptr, slab_stride * KS);
+                             c.assign_pred_b_off[j] >= 0 ? slabs + c.assign_pred_b_off[j] : nullptr, slab_stride * KS,
+                             dS2);
             // assign_pred: logits = Za Wp^T + bp
             {
+                // weight gradient (split-K over the node index, into the slabs) and dZa (whole K per workgroup) in
+                // one launch
                 const int ksn = n >= 256 ? KS : 1;
-                GemmDesc dw{dlog, lv.Za, slabs + c.assign_pred_w_off[j], nullptr, K, li.Da, n, K, li.Da, li.Da,
-                            (long)n * K, (long)n * li.Da, slab_stride * KS, true, false, 1.f, 0.f, 0, slab_stride, 0};
-                bgemm_group(q, &dw, 1, B, ksn);
-                bgemm(q, dlog, PW(params, c.assign_pred_w_off[j]), gr[j].dZa, nullptr, B, n, li.Da, K, K, li.Da, li.Da,
-                      (long)n * K, 0, (long)n * li.Da, false, false, 1.f, 0.f, 0);
+                GemmDesc d2[2] = {
+                    {dlog, lv.Za, slabs + c.assign_pred_w_off[j], nullptr, K, li.Da, n, K, li.Da, li.Da, (long)n * K,
+                     (long)n * li.Da, slab_stride * KS, true, false, 1.f, 0.f, 0, slab_stride, 0},
+                    {dlog, PW(params, c.assign_pred_w_off[j]), gr[j].dZa, nullptr, n, li.Da, K, K, li.Da, li.Da,
+                     (long)n * K, 0, (long)n * li.Da, false, false, 1.f, 0.f, 0, 0, 0, nullptr, 0, 0, 0, 1}};
+                bgemm_group(q, d2, 2, B, ksn);
             }
         }
         level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, KS, Pj, dUj, Gj, part, part_b,

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void k_softmax_mask_bwd(const float* S, int ld
 // gradient) of its rows to the graph's slab row with one float atomic per column and workgroup.
 __global__ __launch_bounds__(256) void k_softmax_mask_bwd_plan(const float* S, int lds, const float* dS, int ldds,
                                                                float* dl, int ldl, int n, int K, float* dbias,
-                                                               long dbias_stride) {
+                                                               long dbias_stride, const float* dS2) {
     extern __shared__ float colsum[];                 // [16 teams][K]
     const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
     const int b = blockIdx.y;
@@ -580,12 +580,13 @@ __global__ __launch_bounds__(256) void k_softmax_mask_bwd_plan(const float* S, i
         const long row = (long)b * n + node;
         const float* s = S + row * lds;
         const float* d = dS + row * ldds;
+        const float* d2 = dS2 ? dS2 + row * ldds : nullptr;     // second addend of the incoming gradient (same ld)
         float dot = 0.f;
-        for (int c = tl; c < K; c += 16) dot += s[c] * d[c];
+        for (int c = tl; c < K; c += 16) dot += s[c] * (d[c] + (d2 ? d2[c] : 0.f));
         dot = team_sum(dot);
         float* o = dl + row * ldl;
         for (int c = tl; c < K; c += 16) {
-            const float v = s[c] * (d[c] - dot);
+            const float v = s[c] * (d[c] + (d2 ? d2[c] : 0.f) - dot);
             o[c] = v;
             mysum[c] += v;
         }
@@ -599,15 +600,17 @@ __global__ __launch_bounds__(256) void k_softmax_mask_bwd_plan(const float* S, i
     }
 }
 void softmax_mask_bwd(Seq& q, const float* S, int lds, const float* dS, int ldds, const int* num_nodes,
-                      float* dlogits, int ldl, int B, int n, int K, float* dbias, long dbias_stride) {
+                      float* dlogits, int ldl, int B, int n, int K, float* dbias, long dbias_stride,
+                      const float* dS2) {
     if (!q.ok()) return;
     const long rows = (long)B * n;
     if (dbias && (size_t)16 * K * sizeof(float) <= 64 * 1024) {
         hipLaunchKernelGGL(k_softmax_mask_bwd_plan, dim3((n + 63) / 64, B), dim3(256), (size_t)16 * K * sizeof(float),
-                           q.stream, S, lds, dS, ldds, dlogits, ldl, n, K, dbias, dbias_stride);
+                           q.stream, S, lds, dS, ldds, dlogits, ldl, n, K, dbias, dbias_stride, dS2);
         q.check_launch("softmax_mask_bwd_plan");
         return;
     }
+    if (dS2) axpy(q, const_cast<float*>(dS), dS2, 1.f, rows * ldds);      // generic path: fold the addend first
     hipLaunchKernelGGL(k_softmax_mask_bwd, dim3(team_grid(rows)), dim3(256), 0, q.stream, S, lds, dS, ldds,
                        num_nodes, dlogits, ldl, rows, n, K);
     q.check_launch("softmax_mask_bwd");
