@@ -182,12 +182,15 @@ void loss_bwd_seq(Seq& q, const float* prob, const long long* label, const float
 }
 
 __global__ void k_add2(float* out, const float* a, const float* b) { out[0] = a[0] + b[0]; out[1] = b[0]; }
-__global__ void k_set2(float* out, const float* a) { out[0] = a[0]; out[1] = 0.f; }
 
 void loss_fwd_seq(Seq& q, const float* ypred, const long long* label, const float* S, const float* adj,
                   const int* num_nodes, float* loss_out, float* prob, int B, int C, int N, int K, int linkpred) {
     float* tmp = q.alloc<float>(64);
     if (q.err) return;
+    if (!linkpred) {                       // loss_out = (CE, 0): one launch
+        ce_fwd(q, ypred, label, loss_out, prob, B, C, loss_out + 1);
+        return;
+    }
     ce_fwd(q, ypred, label, tmp, prob, B, C);
     if (linkpred) {
         linkpred_fwd(q, S, K, adj, num_nodes, tmp + 1, B, N, K);
@@ -195,9 +198,6 @@ void loss_fwd_seq(Seq& q, const float* ypred, const long long* label, const floa
             hipLaunchKernelGGL(k_add2, dim3(1), dim3(1), 0, q.stream, loss_out, tmp, tmp + 1);
             q.check_launch("loss_add");
         }
-    } else if (q.ok()) {
-        hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, q.stream, loss_out, tmp);
-        q.check_launch("loss_set");
     }
 }
 

@@ -180,7 +180,8 @@ void masked_max_fwd(Seq& q, const float* Z, int ldz, const int* num_nodes, float
 void masked_max_bwd(Seq& q, const float* dout, int ldo, const int* argmax, int lda, float* dZ, int ldz, int B,
                     int n, int F);
 void relu_bwd_inplace(Seq& q, float* d, const float* h, long count);
-void ce_fwd(Seq& q, const float* logits, const long long* label, float* loss, float* prob, int B, int C);
+void ce_fwd(Seq& q, const float* logits, const long long* label, float* loss, float* prob, int B, int C,
+            float* also_zero = nullptr /*a second scalar to clear in the same launch*/);
 void ce_bwd(Seq& q, const float* prob, const long long* label, const float* dloss, float scale, float* dlogits,
             int B, int C);
 void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, long count, int accumulate);

@@ -752,7 +752,7 @@ void axpy(Seq& q, float* y, const float* x, float a, long count) {
 // ------------------------------------------------------------------ cross entropy
 // loss = mean_b (logsumexp(logits_b) - logits_b[label_b])   (F.cross_entropy, encoders.py:1127)
 __global__ __launch_bounds__(256) void k_ce_fwd(const float* logits, const long long* label, float* loss,
-                                                float* prob, int B, int C) {
+                                                float* prob, int B, int C, float* also_zero) {
     __shared__ float red[256];
     float acc = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
@@ -773,11 +773,15 @@ __global__ __launch_bounds__(256) void k_ce_fwd(const float* logits, const long 
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = red[0] / (float)B;
+    if (threadIdx.x == 0) {
+        loss[0] = red[0] / (float)B;
+        if (also_zero) also_zero[0] = 0.f;
+    }
 }
-void ce_fwd(Seq& q, const float* logits, const long long* label, float* loss, float* prob, int B, int C) {
+void ce_fwd(Seq& q, const float* logits, const long long* label, float* loss, float* prob, int B, int C,
+            float* also_zero) {
     if (!q.ok()) return;
-    hipLaunchKernelGGL(k_ce_fwd, dim3(1), dim3(256), 0, q.stream, logits, label, loss, prob, B, C);
+    hipLaunchKernelGGL(k_ce_fwd, dim3(1), dim3(256), 0, q.stream, logits, label, loss, prob, B, C, also_zero);
     q.check_launch("ce_fwd");
 }
 __global__ void k_ce_bwd(const float* prob, const long long* label, const float* dloss, float scale, float* dl,

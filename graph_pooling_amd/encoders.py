@@ -450,6 +450,7 @@ class _LossFn(torch.autograd.Function):
         ctx.dims = (B, Cc, N, K, bool(linkpred))
         total, link = out[0], out[1]
         ctx.mark_non_differentiable(link)
+        ctx.set_materialize_grads(False)      # no zero-fill launch for the unused gradient of `link`
         return total, link
 
     @staticmethod
@@ -457,6 +458,8 @@ class _LossFn(torch.autograd.Function):
         lib = _lib.load()
         prob, label, S, adj, num_nodes, ws = ctx.saved
         B, Cc, N, K, linkpred = ctx.dims
+        if dtotal is None:
+            return None, None, None, None, None, None
         dtotal = dtotal.contiguous().float()
         dpred = torch.empty(B, Cc, device=prob.device, dtype=torch.float32)
         dS = torch.empty_like(S) if linkpred else None
