@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void k_adj_pack(const float* A, unsigned short
 
 void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int* flag, int B, int n, int ld) {
     if (!q.ok()) return;
-    q.zero(flag, 256);
+    zero_fill(q, flag, 256);      // (a kernel: captured memset nodes misbehave on replay, see zero_fill)
     const int t = (ld + 63) / 64;
     hipLaunchKernelGGL(k_adj_pack, dim3(t, (n + 63) / 64, B), dim3(256), 0, q.stream, A, P, Pt, flag, n, ld);
     q.check_launch("adj_pack");

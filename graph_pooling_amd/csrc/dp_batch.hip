@@ -52,7 +52,7 @@ void build_batch(Seq& q, const int* src, const int* dst, const int* edge_ptr, co
     if (!q.ok() || B <= 0) return;
     zero_fill(q, adj, (size_t)B * N * N * sizeof(float));
     if (feats) zero_fill(q, feats, (size_t)B * N * F * sizeof(float));
-    q.zero(errors, sizeof(int));
+    zero_small(q, errors, sizeof(int));
     int gx = (max_edges_per_graph + 255) / 256;
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
     hipLaunchKernelGGL(k_scatter_edges, dim3(gx, B), dim3(256), 0, q.stream, src, dst, edge_ptr, node_ptr, adj, B, N,

@@ -70,14 +70,6 @@ struct Seq {
             err = (int)e;
         }
     }
-    void zero(void* p, size_t bytes) {
-        if (err || dry || bytes == 0) return;
-        hipError_t e = hipMemsetAsync(p, 0, bytes, stream);
-        if (e != hipSuccess) {
-            set_error("hipMemsetAsync: %s", hipGetErrorString(e));
-            err = (int)e;
-        }
-    }
 };
 
 inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
@@ -186,7 +178,8 @@ void ce_bwd(Seq& q, const float* prob, const long long* label, const float* dlos
             int B, int C);
 void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, long count, int accumulate);
 void axpy(Seq& q, float* y, const float* x, float a, long count);
-void zero_fill(Seq& q, void* p, size_t bytes);   // wide-store zero kernel (falls back to hipMemsetAsync for odd sizes)
+void zero_fill(Seq& q, void* p, size_t bytes);   // wide-store zero kernel (byte kernel for odd sizes); never a memset node
+void zero_small(Seq& q, void* p, size_t bytes);
 
 // (dp_agg.hip) adjacency-panel aggregation
 struct PackedAdj {               // written by adj_pack: bf16 copies of A and A^T + the exactness flag

@@ -533,7 +533,7 @@ void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, c
     }
     if (fits && (vs || zero_p)) {
         if (zero_p && ((reinterpret_cast<uintptr_t>(zero_p) & 15) != 0 || (zero_bytes & 15) != 0)) {
-            q.zero(zero_p, zero_bytes);
+            zero_small(q, zero_p, zero_bytes);
             zero_p = nullptr;
         }
         SoftmaxFwdArgs a{logits, ldl, S, lds, S2, num_nodes, n, K, vs, (K + 15) / 16, ((n + 31) / 32) * 4,
@@ -708,17 +708,32 @@ void mask_rows(Seq& q, const float* src, int lds, float* dst, int ldd, const int
 }
 
 // ------------------------------------------------------------------ zero fill
-// hipMemsetAsync runs its fill kernel on 256 workgroups whatever the size (17 us for the 4 MB of gradient
-// slabs); a plain wide-store kernel is 3-5x faster at these sizes and is just as capturable.
+// Never hipMemsetAsync on this path.  (1) It runs its fill kernel on 256 workgroups whatever the size (17 us for the
+// 4 MB of gradient slabs); a plain wide-store kernel is 3-5x faster.  (2) A memset node captured into a hipGraph
+// writes garbage from the second replay on with this runtime (ROCm 7.2: the 256-byte pack flag read back
+// 0x633f5c00... after replay 1 — tools/graph_memset_probe.py), which silently sent every captured step down the
+// fp32 fallback of the aggregation kernels.  Kernels only.
 __global__ __launch_bounds__(256) void k_zero16(uint4* p, long n16) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)gridDim.x * 256;
     for (long k = i; k < n16; k += stride) p[k] = make_uint4(0, 0, 0, 0);
 }
+__global__ __launch_bounds__(256) void k_zero_bytes(unsigned char* p, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (long k = i; k < n; k += stride) p[k] = 0;
+}
+void zero_small(Seq& q, void* p, size_t bytes) {
+    if (!q.ok() || bytes == 0) return;
+    long blocks = ((long)bytes + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_zero_bytes, dim3((int)blocks), dim3(256), 0, q.stream, (unsigned char*)p, (long)bytes);
+    q.check_launch("zero_small");
+}
 void zero_fill(Seq& q, void* p, size_t bytes) {
     if (!q.ok() || bytes == 0) return;
-    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0 || (bytes & 15) != 0 || bytes < 4096) {
-        q.zero(p, bytes);
+    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0 || (bytes & 15) != 0) {
+        zero_small(q, p, bytes);
         return;
     }
     const long n16 = (long)(bytes / 16);

@@ -289,3 +289,50 @@ def test_set2set_enzymes_shape_against_oracle():
     named = dict(m.named_parameters())
     for k, v in P.items():
         close(named[k].grad, v.grad, 2e-3, max(2e-5, 2e-4 * float(v.grad.abs().max())))
+
+
+def test_step_is_capturable_in_a_hip_graph_and_replays_bit_identically():
+    """No call of the path allocates, frees or synchronises: forward + loss + backward captured
+    once in a hipGraph must replay to the same bits as the eager step, also after the inputs change in place."""
+    B, N, F_, H, Cc = 6, 160, 7, 12, 3
+    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=20, p=0.05, seed=5, n_classes=Cc)
+    model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, 3, H, assign_ratio=0.2, linkpred=True).cuda()
+    xd, ad, ld = x.cuda(), adj.cuda(), label.cuda()
+    nd = torch.from_numpy(nn_).cuda()                   # device num_nodes: no H2D inside the captured region
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        y = model(xd, ad, nd, assign_x=xd)
+        loss = model.loss(y, ld, ad, nd)
+        loss.backward()
+        return y, loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    model.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g):
+        y_static, loss_static = step()
+    grads_static = {k: p.grad for k, p in model.named_parameters()}
+
+    for seed in (5, 9):                                  # same inputs, then new inputs written in place
+        x2, adj2, nn2, label2 = O.make_batch(B, N, F_, n_min=20, p=0.05, seed=seed, n_classes=Cc)
+        xd.copy_(x2); ad.copy_(adj2); ld.copy_(label2); nd.copy_(torch.from_numpy(nn2))
+        g.replay()
+        torch.cuda.synchronize()
+        y_g, loss_g = y_static.clone(), loss_static.clone()
+        grads_g = {k: v.clone() for k, v in grads_static.items()}
+        y_e, loss_e = step()                             # eager, same inputs
+        close(y_g, y_e, 0, 0)
+        close(loss_g, loss_e, 0, 0)
+        for k, p in model.named_parameters():
+            # bias gradients are sums of float atomics (order can differ in the last place); the rest is bit-exact
+            if k.endswith("bias"):
+                close(grads_g[k], p.grad, 1e-5, 1e-7)
+            else:
+                close(grads_g[k], p.grad, 0, 0)
