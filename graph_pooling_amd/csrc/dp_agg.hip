@@ -914,6 +914,8 @@ void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int
 }
 int adj_pack_ld(int n) { return (n + 7) & ~7; }
 bool adj_pack_supported(int n, int C) {
+    static const bool off = getenv("DP_NO_PACK") != nullptr;      // ablation: fp32 adjacency passes everywhere
+    if (off) return false;
     // worth it only for big levels; the bf16 panel of a 32-row tile must fit LDS beside the reduction area
     return n >= 128 && C >= 1 && C <= AGGW_MAX_C &&
            ((size_t)16 * (((n + 511) / 512) * 512 + 8) * 2 + 5 * 16 * 129 * 4 <= 156 * 1024);
