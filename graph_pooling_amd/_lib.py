@@ -23,7 +23,8 @@ class StackCfg(C.Structure):
     _fields_ = [("n_layers", C.c_int),
                 ("dims", C.c_int * (DP_MAX_LAYERS + 1)),
                 ("w_off", C.c_long * DP_MAX_LAYERS),
-                ("b_off", C.c_long * DP_MAX_LAYERS)]
+                ("b_off", C.c_long * DP_MAX_LAYERS),
+                ("drop_off", C.c_long * DP_MAX_LAYERS)]
 
 
 class EncoderCfg(C.Structure):
@@ -92,8 +93,8 @@ _PROTOS = {
     "dp_mean_aggregate_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "dp_encoder_save_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "dp_encoder_workspace_bytes": (_Z, [C.POINTER(EncoderCfg)]),
-    "dp_encoder_forward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
-    "dp_encoder_backward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
+    "dp_encoder_forward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
+    "dp_encoder_backward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
     "dp_build_batch": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dp_clip_adam_workspace_bytes": (_Z, []),
     "dp_clip_adam_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P, _P, _Z, _P]),

@@ -19,10 +19,11 @@ const char* last_error() { return g_err; }
 
 // dp_model.hip
 int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
-                    const float* assign_x, const int* num_nodes, float* ypred, float* assign_out, void* save);
+                    const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
+                    float* assign_out, void* save);
 int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
-                     const float* assign_x, const int* num_nodes, const float* d_ypred, const float* d_assign,
-                     float* grads, const void* save);
+                     const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
+                     const float* d_assign, float* grads, const void* save);
 size_t encoder_save_bytes(const dp_encoder_cfg& c);
 int encoder_validate(const dp_encoder_cfg* c);
 // dp_set2set.hip
@@ -483,13 +484,14 @@ size_t dp_encoder_save_bytes(const dp_encoder_cfg* cfg) {
 }
 size_t dp_encoder_workspace_bytes(const dp_encoder_cfg* cfg) {
     if (encoder_validate(cfg) != DP_OK) return 0;
-    size_t f = sized([&](Seq& q) { encoder_forward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0); });
-    size_t b = sized([&](Seq& q) { encoder_backward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0); });
+    size_t f = sized([&](Seq& q) { encoder_forward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0); });
+    size_t b = sized([&](Seq& q) { encoder_backward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0); });
     return f > b ? f : b;
 }
 int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
-                       const float* assign_x, const int* num_nodes, float* ypred, float* assign_out, void* save,
-                       size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+                       const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
+                       float* assign_out, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
+                       void* stream) {
     int rc = encoder_validate(cfg);
     if (rc != DP_OK) return rc;
     NOTNULL(params); NOTNULL(x); NOTNULL(adj); NOTNULL(ypred); NOTNULL(save);
@@ -497,19 +499,19 @@ int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const flo
     DP_CHECK_ARG(save_bytes >= encoder_save_bytes(*cfg), "save buffer too small: %zu < %zu", save_bytes,
                  encoder_save_bytes(*cfg));
     Seq q(STREAM(stream), workspace, workspace_bytes);
-    return encoder_forward(q, *cfg, params, x, adj, assign_x, num_nodes, ypred, assign_out, save);
+    return encoder_forward(q, *cfg, params, x, adj, assign_x, num_nodes, dropout, ypred, assign_out, save);
 }
 int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
-                        const float* assign_x, const int* num_nodes, const float* d_ypred, const float* d_assign,
-                        float* grads, const void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
-                        void* stream) {
+                        const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
+                        const float* d_assign, float* grads, const void* save, size_t save_bytes, void* workspace,
+                        size_t workspace_bytes, void* stream) {
     int rc = encoder_validate(cfg);
     if (rc != DP_OK) return rc;
     NOTNULL(params); NOTNULL(x); NOTNULL(adj); NOTNULL(d_ypred); NOTNULL(grads); NOTNULL(save);
     DP_CHECK_ARG(save_bytes >= encoder_save_bytes(*cfg), "save buffer too small: %zu < %zu", save_bytes,
                  encoder_save_bytes(*cfg));
     Seq q(STREAM(stream), workspace, workspace_bytes);
-    return encoder_backward(q, *cfg, params, x, adj, assign_x, num_nodes, d_ypred, d_assign, grads, save);
+    return encoder_backward(q, *cfg, params, x, adj, assign_x, num_nodes, dropout, d_ypred, d_assign, grads, save);
 }
 
 size_t dp_loss_workspace_bytes(int B, int N, int K, int linkpred) {

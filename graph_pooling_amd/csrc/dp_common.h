@@ -178,6 +178,8 @@ void ce_bwd(Seq& q, const float* prob, const long long* label, const float* dlos
             int B, int C);
 void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, long count, int accumulate);
 void axpy(Seq& q, float* y, const float* x, float a, long count);
+void mask_mul(Seq& q, const float* x, int ldx, const float* m, float* out, long rows, int w);
+void mask_axpy(Seq& q, float* dst, int ldd, const float* src, const float* m, long rows, int w);
 void zero_fill(Seq& q, void* p, size_t bytes);   // wide-store zero kernel (byte kernel for odd sizes); never a memset node
 void zero_small(Seq& q, void* p, size_t bytes);
 

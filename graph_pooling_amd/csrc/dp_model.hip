@@ -158,6 +158,8 @@ int validate(const dp_encoder_cfg* c) {
         DP_CHECK_ARG(c->n_nodes[j] > 0, "n_nodes[%d]=%d must be positive (assign_ratio too small?)", j,
                      c->n_nodes[j]);
         for (int l = 0; l <= e.n_layers; ++l) DP_CHECK_ARG(e.dims[l] > 0, "embed[%d].dims[%d] must be > 0", j, l);
+        DP_CHECK_ARG(e.drop_off[0] < 0 && (j >= c->num_pooling || c->assign[j].drop_off[0] < 0),
+                     "level %d: layer 0 (conv_first) takes no dropout mask (encoders.py:1010-1012)", j);
         if (j < c->num_pooling) {
             const dp_stack_cfg& a = c->assign[j];
             DP_CHECK_ARG(a.n_layers == e.n_layers,
@@ -222,7 +224,21 @@ struct LevelIO {
     const float* x0e;  // embed stack input [B, n, dims_e[0]]
     const float* x0a;  // assign stack input [B, n, dims_a[0]]
     const float* adj;  // [B, n, n]
+    const float* drop = nullptr;   // dropout mask buffer (training with dropout > 0) or null
+    float* xm[2] = {nullptr, nullptr};   // scratch [B, n, din] per stack: the masked layer input
 };
+
+// mask of stack gi's layer-l input, or null (GraphConv dropout, encoders.py:962-964)
+const float* drop_mask(const LevelInfo& li, const LevelIO& io, int gi, int l) {
+    const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
+    return (io.drop && st && st->drop_off[l] >= 0) ? io.drop + st->drop_off[l] : nullptr;
+}
+bool level_has_dropout(const LevelInfo& li, const LevelIO& io) {
+    for (int gi = 0; gi < li.G; ++gi)
+        for (int l = 0; l < li.L; ++l)
+            if (drop_mask(li, io, gi, l)) return true;
+    return false;
+}
 
 // P = [x_e W_e | x_a W_a]  for layer l of level li  (one grouped launch)
 void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
@@ -242,6 +258,11 @@ void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const Level
             xin = (g == 0 ? lv.Ze + li.coff_e[l - 1] : lv.Za + li.coff_a[l - 1]);
             ldin = g == 0 ? li.D : li.Da;
         }
+        if (const float* m = drop_mask(li, io, g, l)) {        // x <- dropout(x) for this GraphConv only
+            mask_mul(q, xin, ldin, m, io.xm[g], (long)B * n, din);
+            xin = io.xm[g];
+            ldin = din;
+        }
         const int c0 = g == 0 ? 0 : li.e->dims[l + 1];
         d[g] = GemmDesc{xin, PW(params, st->w_off[l]), Pj + c0, nullptr, n, dout, din, ldin, dout, ct,
                         (long)n * ldin, 0, (long)n * ct, false, false, 1.f, 0.f, 0, 0, 0,
@@ -256,7 +277,7 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
     const int B = c.B, n = li.n;
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
-    if (level_is_small(B, li)) {
+    if (level_is_small(B, li) && !level_has_dropout(li, io)) {
         // pooled level (or tiny graphs): one launch per layer, one workgroup per graph (dp_small.hip)
         float* pbuf[2] = {part, part_b};
         for (int l = 0; l < li.L; ++l) {
@@ -323,13 +344,14 @@ struct LevelGrad {
 
 void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
                     const float* params, const LevelGrad& gr, float* slabs, long slab_stride, int KS, float* Pj,
-                    float* dUj, float* Gj, float* part, float* part_b, const PackedAdj* pk, unsigned short* vs) {
+                    float* dUj, float* Gj, float* part, float* part_b, const PackedAdj* pk, unsigned short* vs,
+                    float* const dxm[2]) {
     const int B = c.B, n = li.n;
     const long gstride = slab_stride * KS;     // slab rows of one graph: KS split-K partials
     const int ks_level = n >= 256 ? KS : 1;
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
-    if (level_is_small(B, li)) {
+    if (level_is_small(B, li) && !level_has_dropout(li, io)) {
         float* pbuf[2] = {part, part_b};
         for (int l = li.L - 1; l >= 0; --l) {
             const bool last = l == li.L - 1;
@@ -388,6 +410,9 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
         {
             GemmDesc d[4];
             int nd = 0;
+            float* masked_dst[2] = {nullptr, nullptr};
+            const float* masked_m[2] = {nullptr, nullptr};
+            int masked_ld[2] = {0, 0}, masked_w[2] = {0, 0};
             for (int gi = 0; gi < li.G; ++gi) {
                 const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
                 const int din = st->dims[l], dout = st->dims[l + 1];
@@ -399,6 +424,12 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
                 } else {
                     xin = gi == 0 ? lv.Ze + li.coff_e[l - 1] : lv.Za + li.coff_a[l - 1];
                     ldin = gi == 0 ? li.D : li.Da;
+                }
+                const float* m = drop_mask(li, io, gi, l);
+                if (m) {                                   // the GraphConv saw dropout(x): recompute it
+                    mask_mul(q, xin, ldin, m, io.xm[gi], (long)B * n, din);
+                    xin = io.xm[gi];
+                    ldin = din;
                 }
                 // dW slab[b] = x_in[b]^T G[b]
                 d[nd++] = GemmDesc{xin, Gj + g.c0[gi], slabs + st->w_off[l], nullptr, din, dout, n, ldin, ct, dout,
@@ -413,12 +444,24 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
                     dxin = gr.dX0;
                     lddx = din;
                 }
-                if (dxin)   // accumulates into dZ: atomic so split-K ranges (only > 1 for wide layers) cannot race
+                if (dxin && m) {
+                    // through the mask: G W^T into scratch (plain store, whole K per workgroup), masked add below
+                    masked_dst[gi] = dxin;
+                    masked_ld[gi] = lddx;
+                    masked_m[gi] = m;
+                    masked_w[gi] = din;
+                    d[nd++] = GemmDesc{Gj + g.c0[gi], PW(params, st->w_off[l]), dxm[gi], nullptr, n, din, dout, ct, dout,
+                                       din, (long)n * ct, 0, (long)n * din, false, true, 1.f, 0.f, 0, 0, 0, nullptr, 0, 0,
+                                       0, 1};
+                } else if (dxin)   // accumulates into dZ: atomic so split-K ranges (only > 1 for wide layers) cannot race
                     d[nd++] = GemmDesc{Gj + g.c0[gi], PW(params, st->w_off[l]), dxin, nullptr, n, din, dout, ct, dout,
                                        lddx, (long)n * ct, 0, (long)n * lddx, false, true, 1.f, 1.f, 0, 0,
                                        ks_level > 1 ? 1 : 0};
             }
             bgemm_group(q, d, nd, B, ks_level);
+            for (int gi = 0; gi < li.G; ++gi)
+                if (masked_dst[gi])
+                    mask_axpy(q, masked_dst[gi], masked_ld[gi], dxm[gi], masked_m[gi], (long)B * n, masked_w[gi]);
             // both stacks of a pooled level read the same input X_j: the assign stack's share is added after
             if (l == 0 && gr.dX0 && li.G == 2) {
                 const dp_stack_cfg* st = li.a;
@@ -435,7 +478,25 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
     }
 }
 
+// floats of one masked-input scratch buffer (0 when no stack of the model has a dropout mask)
+size_t dropout_scratch_floats(const dp_encoder_cfg& c) {
+    size_t mx = 0;
+    for (int j = 0; j <= c.num_pooling; ++j) {
+        const LevelInfo li = level_info(c, j);
+        for (int gi = 0; gi < li.G; ++gi) {
+            const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
+            for (int l = 0; l < li.L; ++l)
+                if (st->drop_off[l] >= 0) {
+                    const size_t f = (size_t)c.B * li.n * st->dims[l];
+                    mx = f > mx ? f : mx;
+                }
+        }
+    }
+    return mx;
+}
+
 struct Scratch {
+    float* xm[2];
     float *Pj, *Uj, *part, *part_b, *logits;
     unsigned short* vs;      // 3-plane bf16 split of the current V operand (level 0, packed adjacency)
 };
@@ -490,13 +551,17 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
     s.part_b = q.alloc<float>(maxPart);
     s.logits = q.alloc<float>(maxLog > 0 ? maxLog : 1);
     s.vs = q.alloc<unsigned short>(vs_elems(c));
+    const size_t dsf = dropout_scratch_floats(c);
+    s.xm[0] = dsf ? q.alloc<float>(dsf) : nullptr;
+    s.xm[1] = dsf ? q.alloc<float>(dsf) : nullptr;
     return s;
 }
 
 }  // namespace
 
 int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
-                    const float* assign_x, const int* num_nodes, float* ypred, float* assign_out, void* save) {
+                    const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
+                    float* assign_out, void* save) {
     SaveLayout sv = layout_save(c, save);
     Scratch sc = fwd_scratch(q, c);
     if (q.err) return q.err;
@@ -516,6 +581,9 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
         io.x0e = j == 0 ? x : sv.lv[j - 1].Xn;
         io.x0a = j == 0 ? assign_x : sv.lv[j - 1].Xn;
         io.adj = j == 0 ? adj : sv.lv[j - 1].An;
+        io.drop = dropout;
+        io.xm[0] = sc.xm[0];
+        io.xm[1] = sc.xm[1];
         level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part, sc.part_b, j == 0 ? pkp : nullptr, sc.vs);
         const int* nn_j = (j == 0) ? num_nodes : nullptr;
         if (c.readout == 0) {
@@ -577,8 +645,8 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
 }
 
 int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
-                     const float* assign_x, const int* num_nodes, const float* d_ypred, const float* d_assign,
-                     float* grads, const void* save) {
+                     const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
+                     const float* d_assign, float* grads, const void* save) {
     SaveLayout sv = layout_save(c, (void*)save);
     const int B = c.B, P = c.num_pooling;
     // ---- workspace walk
@@ -616,6 +684,9 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     float* dlog = q.alloc<float>(maxSK ? maxSK : 1);
     float* V = q.alloc<float>(maxSK ? maxSK : 1);
     float* V2 = q.alloc<float>(maxSK ? maxSK : 1);
+    const size_t dsf = dropout_scratch_floats(c);
+    float* xm[2] = {dsf ? q.alloc<float>(dsf) : nullptr, dsf ? q.alloc<float>(dsf) : nullptr};
+    float* dxm[2] = {dsf ? q.alloc<float>(dsf) : nullptr, dsf ? q.alloc<float>(dsf) : nullptr};
     float* dh[DP_MAX_PRED + 2];
     for (int i = 0; i < c.n_pred; ++i) dh[i] = q.alloc<float>((size_t)B * c.pred_dims[i]);
     dh[c.n_pred] = const_cast<float*>(d_ypred);   // read only
@@ -694,6 +765,9 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
         io.x0e = j == 0 ? x : sv.lv[j - 1].Xn;
         io.x0a = j == 0 ? assign_x : sv.lv[j - 1].Xn;
         io.adj = j == 0 ? adj : sv.lv[j - 1].An;
+        io.drop = dropout;
+        io.xm[0] = xm[0];
+        io.xm[1] = xm[1];
         const int n = li.n;
         if (j < P) {
             const int K = li.K, D = li.D;
@@ -750,7 +824,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
             }
         }
         level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, KS, Pj, dUj, Gj, part, part_b,
-                       j == 0 ? pkp : nullptr, vs);
+                       j == 0 ? pkp : nullptr, vs, dxm);
     }
     reduce_slabs(q, slabs, slab_stride, B * KS, grads, c.n_graph_params, 0);
     return q.err;

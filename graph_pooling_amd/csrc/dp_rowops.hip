@@ -707,6 +707,42 @@ void mask_rows(Seq& q, const float* src, int lds, float* dst, int ldd, const int
     q.check_launch("mask_rows");
 }
 
+// ------------------------------------------------------------------ layer-input dropout
+// out[row, :w] = x[row, :w] * m[row, :w]   (m holds 0 or 1/(1-p): nn.Dropout on a GraphConv input, encoders.py:962-964)
+__global__ __launch_bounds__(256) void k_mask_mul(const float* x, int ldx, const float* m, float* out, long rows,
+                                                  int w) {
+    const long total = rows * w;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / w;
+        const int c = (int)(e % w);
+        out[e] = x[row * ldx + c] * m[e];
+    }
+}
+// dst[row, :w] += src[row, :w] * m[row, :w]   (gradient through the same mask)
+__global__ __launch_bounds__(256) void k_mask_axpy(float* dst, int ldd, const float* src, const float* m, long rows,
+                                                   int w) {
+    const long total = rows * w;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / w;
+        const int c = (int)(e % w);
+        dst[row * ldd + c] += src[e] * m[e];
+    }
+}
+void mask_mul(Seq& q, const float* x, int ldx, const float* m, float* out, long rows, int w) {
+    if (!q.ok() || rows <= 0) return;
+    long blocks = (rows * w + 255) / 256;
+    hipLaunchKernelGGL(k_mask_mul, dim3((int)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, q.stream, x, ldx, m, out,
+                       rows, w);
+    q.check_launch("mask_mul");
+}
+void mask_axpy(Seq& q, float* dst, int ldd, const float* src, const float* m, long rows, int w) {
+    if (!q.ok() || rows <= 0) return;
+    long blocks = (rows * w + 255) / 256;
+    hipLaunchKernelGGL(k_mask_axpy, dim3((int)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, q.stream, dst, ldd, src, m,
+                       rows, w);
+    q.check_launch("mask_axpy");
+}
+
 // ------------------------------------------------------------------ zero fill
 // Never hipMemsetAsync on this path.  (1) It runs its fill kernel on 256 workgroups whatever the size (17 us for the
 // 4 MB of gradient slabs); a plain wide-store kernel is 3-5x faster.  (2) A memset node captured into a hipGraph

@@ -114,6 +114,8 @@ def _fill_stack(cfg_stack, dims, w_offs, b_offs):
     cfg_stack.n_layers = len(dims) - 1
     for i, d in enumerate(dims):
         cfg_stack.dims[i] = int(d)
+    for i in range(_lib.DP_MAX_LAYERS):
+        cfg_stack.drop_off[i] = -1
     for i in range(len(dims) - 1):
         cfg_stack.w_off[i] = int(w_offs[i])
         cfg_stack.b_off[i] = int(b_offs[i])
@@ -123,7 +125,7 @@ class _EncoderFn(torch.autograd.Function):
     """One FFI call per pass: dp_encoder_forward / dp_encoder_backward."""
 
     @staticmethod
-    def forward(ctx, owner, x, adj, assign_x, num_nodes, *params):
+    def forward(ctx, owner, x, adj, assign_x, num_nodes, drop, *params):
         lib = _lib.load()
         plan = owner._plan(x.shape[0], x.shape[1], x.device)
         B = plan.cfg.B
@@ -135,11 +137,11 @@ class _EncoderFn(torch.autograd.Function):
         save = torch.empty(plan.save_bytes, device=x.device, dtype=torch.uint8) if needs_grad else plan.eval_save()
         stream = _lib.current_stream()
         _lib.check(lib.dp_encoder_forward(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(), adj.data_ptr(),
-                                          _lib.ptr(assign_x), _lib.ptr(num_nodes), ypred.data_ptr(),
+                                          _lib.ptr(assign_x), _lib.ptr(num_nodes), _lib.ptr(drop), ypred.data_ptr(),
                                           _lib.ptr(assign), save.data_ptr(), plan.save_bytes,
                                           plan.workspace.data_ptr(), plan.ws_bytes, stream), "dp_encoder_forward")
         ctx.owner, ctx.plan, ctx.save = owner, plan, save
-        ctx.inputs = (x, adj, assign_x, num_nodes)
+        ctx.inputs = (x, adj, assign_x, num_nodes, drop)
         ctx.set_materialize_grads(False)
         if assign is None:
             return ypred
@@ -149,7 +151,7 @@ class _EncoderFn(torch.autograd.Function):
     def backward(ctx, d_ypred, d_assign=None):
         lib = _lib.load()
         owner, plan = ctx.owner, ctx.plan
-        x, adj, assign_x, num_nodes = ctx.inputs
+        x, adj, assign_x, num_nodes, drop = ctx.inputs
         if d_ypred is None:
             d_ypred = torch.zeros(plan.cfg.B, plan.label_dim, device=x.device, dtype=torch.float32)
         d_ypred = d_ypred.contiguous()
@@ -157,12 +159,12 @@ class _EncoderFn(torch.autograd.Function):
             d_assign = d_assign.contiguous()
         grads = torch.empty(plan.cfg.n_params, device=x.device, dtype=torch.float32)
         _lib.check(lib.dp_encoder_backward(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(), adj.data_ptr(),
-                                           _lib.ptr(assign_x), _lib.ptr(num_nodes), d_ypred.data_ptr(),
+                                           _lib.ptr(assign_x), _lib.ptr(num_nodes), _lib.ptr(drop), d_ypred.data_ptr(),
                                            _lib.ptr(d_assign), grads.data_ptr(), ctx.save.data_ptr(),
                                            plan.save_bytes, plan.workspace.data_ptr(), plan.ws_bytes,
                                            _lib.current_stream()), "dp_encoder_backward")
         owner._last_flat_grad = grads
-        out = [None, None, None, None, None]
+        out = [None, None, None, None, None, None]
         for (off, numel, shape) in owner._flat_index:
             out.append(grads[off:off + numel].view(shape))
         return tuple(out)
@@ -174,6 +176,7 @@ class _Plan:
     def __init__(self, owner, B, N, device):
         lib = _lib.load()
         self.cfg = owner._build_cfg(B, N)
+        self.drop_segments, self.drop_total = owner._fill_dropout(self.cfg, B)
         self.label_dim = owner.label_dim
         self.save_bytes = lib.dp_encoder_save_bytes(C.byref(self.cfg))
         self.ws_bytes = lib.dp_encoder_workspace_bytes(C.byref(self.cfg))
@@ -370,19 +373,43 @@ class GcnEncoderGraph(nn.Module):
             self._plans[key] = plan
         return plan
 
-    def _check_dropout(self):
-        if self.training:
-            for m in self.modules():
-                if isinstance(m, GraphConv) and m.dropout > 0.001:
-                    raise NotImplementedError("dropout > 0 in training mode is not implemented in the fused HIP "
-                                              "path yet (train.py default is 0.0)")
+    def _fill_dropout(self, cfg, B):
+        """GraphConv layers built with dropout > 0 (the conv_block layers of the after-pool stacks of DiffPool, of
+        the only stack of the base encoders, when the model is constructed with dropout: encoders.py:1013-1016,
+        1180-1183) apply nn.Dropout to their INPUT
+        (encoders.py:962-964).  Give each such layer a slot [B, n, d_in] in one mask buffer and record its offset
+        in the stack config; returns ([(offset, numel, p)], total floats)."""
+        segs, total = [], 0
+        n_level = [int(cfg.n_nodes[j]) for j in range(cfg.num_pooling + 1)]
+        for kind, lvl, mods in self._graph_param_groups():
+            if kind not in ("embed", "assign"):
+                continue
+            st = cfg.embed[lvl] if kind == "embed" else cfg.assign[lvl]
+            for l, m in enumerate(mods):
+                if m.dropout > 0.001:
+                    if l == 0:
+                        raise NotImplementedError("dropout on the first GraphConv of a stack (the reference never "
+                                                  "builds one, encoders.py:1010-1012)")
+                    numel = B * n_level[lvl] * m.input_dim
+                    st.drop_off[l] = total
+                    segs.append((total, numel, float(m.dropout)))
+                    total += numel
+        return segs, total
+
+    def _draw_dropout(self, plan, device):
+        """Fresh masks for one training step: 0 or 1/(1-p), torch's generator on the device."""
+        if not (self.training and plan.drop_total):
+            return None
+        drop = torch.empty(plan.drop_total, device=device, dtype=torch.float32)
+        for off, numel, p in plan.drop_segments:
+            drop[off:off + numel].bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+        return drop
 
     def _run(self, x, adj, batch_num_nodes, assign_x=None):
         _lib.require_gpu_tensor(x, "x")
         _lib.require_gpu_tensor(adj, "adj")
         if x.dim() != 3 or adj.dim() != 3 or adj.shape[1] != adj.shape[2] or adj.shape[:2] != x.shape[:2]:
             raise ValueError(f"expected x [B,N,F] and adj [B,N,N], got {tuple(x.shape)} and {tuple(adj.shape)}")
-        self._check_dropout()
         x = x.contiguous().float()
         adj = adj.contiguous().float()
         if assign_x is not None:
@@ -391,7 +418,10 @@ class GcnEncoderGraph(nn.Module):
         nn_dev = _num_nodes_device(batch_num_nodes, x.device)
         if nn_dev is not None and nn_dev.numel() != x.shape[0]:
             raise ValueError("batch_num_nodes must have one entry per graph")
-        return _EncoderFn.apply(self, x, adj, assign_x, nn_dev, *self._flat_params)
+        drop = getattr(self, "_forced_dropout_mask", None)       # tests inject the oracle's masks here
+        if drop is None:
+            drop = self._draw_dropout(self._plan(x.shape[0], x.shape[1], x.device), x.device)
+        return _EncoderFn.apply(self, x, adj, assign_x, nn_dev, drop, *self._flat_params)
 
     # -- reference surface
     def construct_mask(self, max_nodes, batch_num_nodes):

@@ -199,6 +199,9 @@ typedef struct {
     int dims[DP_MAX_LAYERS + 1];     /* dims[0] = input width, dims[l] = output width of layer l */
     long w_off[DP_MAX_LAYERS];       /* weight [dims[l], dims[l+1]] offset in the flat buffer */
     long b_off[DP_MAX_LAYERS];       /* bias [dims[l+1]] offset, or -1 */
+    long drop_off[DP_MAX_LAYERS];    /* layer-input dropout (GraphConv.forward, encoders.py:962-964): offset in the
+                                        `dropout` buffer of a mask [B, n, dims[l]] holding 0 or 1/(1-p), or -1.
+                                        Layer 0 (conv_first) has none in the reference; must be -1. */
 } dp_stack_cfg;
 
 typedef struct {
@@ -233,14 +236,16 @@ size_t dp_encoder_workspace_bytes(const dp_encoder_cfg* cfg);
  * num_pooling = 0) and GcnSet2SetEncoder.forward (:1144-1157, readout = 1).
  * x [B,N,F], adj [B,N,N], assign_x [B,N,Fa] (may alias x), num_nodes int32[B] or NULL.
  * ypred [B,label_dim]; assign_out [B,N,K_0] (level-0 S, = assign_tensor when P = 1) or NULL when
- * P = 0; `save` keeps activations for backward. */
+ * P = 0; `save` keeps activations for backward.  dropout: the mask buffer addressed by the stacks' drop_off
+ * (training with GraphConv dropout > 0; the caller draws the masks and passes the SAME buffer to backward), or
+ * NULL (evaluation, or dropout 0: every drop_off is ignored). */
 int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
-                       const float* assign_x, const int* num_nodes, float* ypred, float* assign_out,
-                       void* save, size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+                       const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
+                       float* assign_out, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
 /* d_ypred [B,label_dim]; d_assign [B,N,K_0] or NULL (gradient arriving at the level-0 assignment
  * from the link-prediction loss); grads: flat, same layout as params, OVERWRITTEN. */
 int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
-                        const float* assign_x, const int* num_nodes, const float* d_ypred,
+                        const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
                         const float* d_assign, float* grads, const void* save, size_t save_bytes,
                         void* workspace, size_t workspace_bytes, void* stream);
 

@@ -99,13 +99,17 @@ def _stack_keys(first: str, block: str, last: str, n_layers: int) -> List[str]:
 
 
 def gcn_stack(x: Tensor, adj: Tensor, params: Dict[str, Tensor], keys: Sequence[str],
-              mask: Optional[Tensor], bn: bool = True, add_self: bool = False) -> Tensor:
+              mask: Optional[Tensor], bn: bool = True, add_self: bool = False,
+              drop: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """All-layer GCN with ReLU+BN between layers, concat over layers, optional mask.
-    Follows encoders.py:1054-1081 (gcn_forward)."""
+    Follows encoders.py:1054-1081 (gcn_forward).  `drop[k]` (values 0 or 1/(1-p), shape of layer k's input) stands
+    for the nn.Dropout a GraphConv built with dropout > 0 applies to its input (encoders.py:962-964): the layer sees
+    h * drop[k], the concat keeps the un-dropped h."""
     outs = []
     h = x
     for li, k in enumerate(keys):
-        h = graph_conv(h, adj, params[k + ".weight"], params.get(k + ".bias"), add_self, True)
+        hin = h * drop[k] if (drop is not None and k in drop) else h
+        h = graph_conv(hin, adj, params[k + ".weight"], params.get(k + ".bias"), add_self, True)
         if li < len(keys) - 1:
             h = torch.relu(h)
             if bn:
@@ -153,7 +157,7 @@ def level_keys(level: int, num_pooling: int, n_layers: int):
 def softpool_forward(params: Dict[str, Tensor], x: Tensor, adj: Tensor, num_nodes,
                      assign_x: Optional[Tensor] = None, *, num_layers: int = 3,
                      num_pooling: int = 1, n_pred_hidden: int = 1, bn: bool = True,
-                     want_intermediates: bool = False):
+                     want_intermediates: bool = False, drop: Optional[Dict[str, Tensor]] = None):
     """SoftPoolingGcnEncoder.forward, encoders.py:1231-1300, with the index fixes of
     SURVEY.md Appendix B (D3: per-level assign_pred; D4: level>=1 assign input = X').
 
@@ -167,13 +171,13 @@ def softpool_forward(params: Dict[str, Tensor], x: Tensor, adj: Tensor, num_node
     mask = node_mask(N, num_nodes, x.dtype) if num_nodes is not None else None
     inter = {}
     emb0 = _stack_keys("conv_first", "conv_block", "conv_last", num_layers)
-    z = gcn_stack(x, adj, params, emb0, mask, bn)                       # :1254
+    z = gcn_stack(x, adj, params, emb0, mask, bn, drop=drop)            # :1254
     outs = [z.max(dim=1)[0]]                                            # :1257
     s0 = None
     for i in range(num_pooling):                                        # :1263
         emb_k, asg_k, pred_k = level_keys(i, num_pooling, num_layers)
         m = mask if i == 0 else None                                    # :1264-1267
-        za = gcn_stack(x_a, adj, params, asg_k, m, bn)                  # :1269-1271
+        za = gcn_stack(x_a, adj, params, asg_k, m, bn, drop=drop)       # :1269-1271
         logits = F.linear(za, params[pred_k + ".weight"], params[pred_k + ".bias"])
         s = torch.softmax(logits, dim=-1)                               # :1273
         if m is not None:
@@ -187,7 +191,7 @@ def softpool_forward(params: Dict[str, Tensor], x: Tensor, adj: Tensor, num_node
             inter[f"assign_{i}"] = s
             inter[f"xpool_{i}"] = xp
             inter[f"adjpool_{i}"] = adj
-        z = gcn_stack(xp, adj, params, emb_k, None, bn)                 # :1282-1284
+        z = gcn_stack(xp, adj, params, emb_k, None, bn, drop=drop)      # :1282-1284
         outs.append(z.max(dim=1)[0])                                    # :1287
         inter["assign_last"] = s
     feat = torch.cat(outs, dim=1)                                       # :1295-1296
@@ -226,15 +230,17 @@ def softpool_loss(ypred: Tensor, label: Tensor, s0: Optional[Tensor] = None,
 
 # -------------------------------------------------------------------------- A11
 def base_forward(params: Dict[str, Tensor], x: Tensor, adj: Tensor, *, num_layers: int = 3,
-                 n_pred_hidden: int = 0, bn: bool = True, concat: bool = True) -> Tensor:
+                 n_pred_hidden: int = 0, bn: bool = True, concat: bool = True,
+                 drop: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """GcnEncoderGraph.forward, encoders.py:1083-1122: per-layer max readout, no
-    masking at all (the mask is built at :1087 but never used)."""
+    masking at all (the mask is built at :1087 but never used).  `drop`: see gcn_stack."""
     add_self = not concat
     keys = _stack_keys("conv_first", "conv_block", "conv_last", num_layers)
     h = x
     outs = []
     for li, k in enumerate(keys):
-        h = graph_conv(h, adj, params[k + ".weight"], params.get(k + ".bias"), add_self, True)
+        hin = h * drop[k] if (drop is not None and k in drop) else h
+        h = graph_conv(hin, adj, params[k + ".weight"], params.get(k + ".bias"), add_self, True)
         if li < num_layers - 1:
             h = torch.relu(h)
             if bn:
