@@ -36,6 +36,13 @@ WORKLOADS = {
                name="S-DD: DD-shaped padded batch, B=20/GPU, N_max=500, F=89, H=E=20, K=50, L=3, 1 pool"),
     "enzymes": dict(B=20, N=100, F=3, H=20, C=6, ratio=0.1, p=0.10, n_min=10, onehot=True,
                     name="S-ENZ: ENZYMES-shaped padded batch, B=20/GPU, N=100, F=3, H=E=20, K=10"),
+    # BASELINE configs[4] ("ENZYMES with Set2Set global readout + 3 pooling levels") is two models in the reference
+    # (SURVEY Appendix E.4): GcnSet2SetEncoder without pooling, and SoftPoolingGcnEncoder with max readout
+    "enzymes_s2s": dict(B=20, N=100, F=3, H=20, C=6, ratio=0.1, p=0.10, n_min=10, onehot=True, model="set2set",
+                        name="S-S2S: ENZYMES-shaped batch through GcnSet2SetEncoder (Set2Set readout, no pooling)"),
+    "enzymes_p3": dict(B=20, N=100, F=3, H=20, C=6, ratio=0.25, p=0.10, n_min=10, onehot=True, num_pooling=3,
+                       name="S-ENZ-P3: ENZYMES-shaped batch, SoftPoolingGcnEncoder with 3 pooling levels K=25,6,1 "
+                            "(build-defined semantics, SURVEY Appendix B)"),
     "er": dict(B=256, N=1024, F=64, H=20, C=2, ratio=0.25, p=0.01, n_min=1024, onehot=False, num_pooling=2, roofline="mfma",
                name="S-ER: Erdos-Renyi B=256, N=1024, F=64, H=E=20, 2 pooling levels K=256->64 (SURVEY 8d)"),
 }
@@ -65,11 +72,14 @@ def synthetic_batch(w, seed):
 
 
 def make_model_and_batch(w, linkpred, device, seed_offset=0):
-    from graph_pooling_amd.encoders import SoftPoolingGcnEncoder
+    from graph_pooling_amd.encoders import GcnSet2SetEncoder, SoftPoolingGcnEncoder
     x, adj, nn_, label = synthetic_batch(w, seed=1 + seed_offset)
     torch.manual_seed(0)             # reference init (encoders.py:1225-1229: xavier GraphConv, default nn.Linear)
-    model = SoftPoolingGcnEncoder(w["N"], w["F"], w["H"], w["H"], w["C"], 3, w["H"], assign_ratio=w["ratio"],
-                                  num_pooling=w.get("num_pooling", 1), linkpred=linkpred)
+    if w.get("model") == "set2set":
+        model = GcnSet2SetEncoder(w["F"], w["H"], w["H"], w["C"], 3)
+    else:
+        model = SoftPoolingGcnEncoder(w["N"], w["F"], w["H"], w["H"], w["C"], 3, w["H"], assign_ratio=w["ratio"],
+                                      num_pooling=w.get("num_pooling", 1), linkpred=linkpred)
     params = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(device)
     batch = dict(x=x.to(device), adj=adj.to(device), nn=nn_.to(device), label=label.to(device))
@@ -88,9 +98,13 @@ def cpu_baseline(cpu, w, linkpred, budget_s=15.0):
     def step():
         for v in P.values():
             v.grad = None
-        y, inter = O.softpool_forward(P, cpu["x"], cpu["adj"], cpu["nn"], cpu["x"],
-                                      num_pooling=w.get("num_pooling", 1))
-        loss, _ = O.softpool_loss(y, cpu["label"], inter["assign_0"], cpu["adj"], cpu["nn"], linkpred)
+        if w.get("model") == "set2set":
+            y = O.set2set_encoder_forward(P, cpu["x"], cpu["adj"], cpu["nn"], num_layers=3)
+            loss = torch.nn.functional.cross_entropy(y, cpu["label"])
+        else:
+            y, inter = O.softpool_forward(P, cpu["x"], cpu["adj"], cpu["nn"], cpu["x"],
+                                          num_pooling=w.get("num_pooling", 1))
+            loss, _ = O.softpool_loss(y, cpu["label"], inter["assign_0"], cpu["adj"], cpu["nn"], linkpred)
         loss.backward()
 
     cands = sorted({t for t in (1, 8, 16, 32) if t <= ncpu})

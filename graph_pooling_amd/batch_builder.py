@@ -70,9 +70,39 @@ class EdgeListDataset:
 
 
 class DeviceBatchBuilder:
+    _RING = 4          # pinned staging buffers in rotation (a buffer is reused only after its copy has completed)
+
     def __init__(self, dataset: EdgeListDataset, max_nodes: int, feat_dim: int, device="cuda"):
         self.ds, self.N, self.F = dataset, int(max_nodes), int(feat_dim)
         self.device = torch.device(device)
+        self._stage = [None] * self._RING       # (pinned int32 tensor, event)
+        self._turn = 0
+
+    def _to_device(self, parts):
+        """ONE host->device copy of all int32 arrays back to back, through a reusable pinned buffer (pinning per
+        call costs milliseconds — more than the whole training step)."""
+        total = sum(len(p) for p in parts)
+        dev = self.device
+        if dev.type != "cuda":
+            return torch.from_numpy(np.concatenate(parts).astype(np.int32)).to(dev)
+        slot = self._turn % self._RING
+        self._turn += 1
+        buf, ev = self._stage[slot] if self._stage[slot] is not None else (None, None)
+        if buf is None or buf.numel() < total:
+            buf = torch.empty(max(total, 1 << 16), dtype=torch.int32).pin_memory()
+            ev = torch.cuda.Event()
+        else:
+            ev.synchronize()                     # the copy that last used this buffer is done
+        view = buf.numpy()
+        o = 0
+        for p in parts:
+            view[o:o + len(p)] = p
+            o += len(p)
+        packed = torch.empty(total, device=dev, dtype=torch.int32)
+        packed.copy_(buf[:total], non_blocking=True)
+        ev.record(torch.cuda.current_stream(dev))
+        self._stage[slot] = (buf, ev)
+        return packed
 
     def build(self, indices: Sequence[int], check: bool = True) -> Dict[str, object]:
         """Device tensors `adj`, `feats` (= `assign_feats`), `label`, plus `num_nodes` as the host int array the
@@ -90,13 +120,9 @@ class DeviceBatchBuilder:
         if len(lab) and (int(lab.min()) < 0 or int(lab.max()) >= self.F):
             raise ValueError(f"node label outside [0, {self.F})")
         dev = self.device
-        # ONE host->device copy: all int32 arrays back to back
         parts = [src, dst, edge_ptr, lab, node_ptr]
         offs = np.cumsum([0] + [len(p) for p in parts])
-        host = torch.from_numpy(np.concatenate(parts).astype(np.int32))
-        if dev.type == "cuda":
-            host = host.pin_memory()
-        packed = host.to(dev, non_blocking=True)
+        packed = self._to_device(parts)
         view = [packed[offs[i]:offs[i + 1]] for i in range(len(parts))]
         adj = torch.empty(B, self.N, self.N, device=dev, dtype=torch.float32)
         feats = torch.empty(B, self.N, self.F, device=dev, dtype=torch.float32)
@@ -109,6 +135,6 @@ class DeviceBatchBuilder:
                                       self.F, 1, max_edges, _lib.current_stream()), "dp_build_batch")
         if check and int(errors.item()) != 0:
             raise RuntimeError(f"dp_build_batch skipped {int(errors.item())} out-of-range entries")
-        label = torch.from_numpy(glabel).to(dev, non_blocking=True)
+        label = torch.from_numpy(np.ascontiguousarray(glabel)).to(dev)
         return {"adj": adj, "feats": feats, "assign_feats": feats, "label": label,
                 "num_nodes": n.astype(np.int32), "num_nodes_device": nn_dev}
