@@ -86,6 +86,7 @@ struct S2SFwdArgs {
     float *QP, *H, *Cs, *G, *Aw, *QN;   // save arrays (may be null: inference)
     int n, d, GS;
     int w_in_lds;
+    int emb_in_lds;        // the graph's embedding [n][d] is staged once and every step reads LDS (it fits beside W)
 };
 
 __global__ __launch_bounds__(256) void k_set2set_fwd(S2SFwdArgs a) {
@@ -101,24 +102,46 @@ __global__ __launch_bounds__(256) void k_set2set_fwd(S2SFwdArgs a) {
     float* red = gates + 4 * d;                        // [8]
     float* rpart = red + 8;                            // [4][64]
     float* al = rpart + 256;                           // [n]
+    float* le = al + ((n + 15) & ~15);                 // [n][d] when emb_in_lds
     const float* W = a.w_in_lds ? lw : a.wt;
     if (a.w_in_lds)
         for (int i = tid; i < 2 * d * GS; i += 256) lw[i] = a.wt[i];
     for (int i = tid; i < 3 * d; i += 256) vec[i] = 0.f;       // h, c, r = 0 (set2set.py:42-45)
-    __syncthreads();
     const float* emb = a.emb + (long)b * n * a.lde;
+    int lde = a.lde;
+    if (a.emb_in_lds) {
+        // the 2 n passes over the embedding (e = emb h, r = a^T emb, every step) were global reads: ~7 dependent
+        // L2 round trips per step, most of the step's time at n = 100
+        for (int i = tid; i < n * d; i += 256) le[i] = emb[(long)(i / d) * a.lde + i % d];
+        emb = le;
+        lde = d;
+    }
+    __syncthreads();
     const int tl = tid & 15, team = tid >> 4;
+    // per-thread gate biases (were two global loads per gate per step, at the head of every step's critical path)
+    constexpr int GPT = 4;                            // gates per thread: 4d <= 1024
+    float gbias[GPT];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+        const int g = tid + 256 * i;
+        gbias[i] = g < 4 * d ? a.b_ih[g] + a.b_hh[g] : 0.f;
+    }
 
     for (int t = 0; t < n; ++t) {
         // ---- q*_{t-1} = [h, r] is the LSTM input of this step
         if (a.QP)
             for (int i = tid; i < 2 * d; i += 256) a.QP[((long)b * n + t) * 2 * d + i] = i < d ? h[i] : r[i - d];
         // ---- gates = b + Wc h + Wr r
-        for (int g = tid; g < 4 * d; g += 256) {
-            float acc = a.b_ih[g] + a.b_hh[g];
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const int g = tid + 256 * i;
+            if (g >= 4 * d) break;
+            float acc = gbias[i], acc2 = 0.f;
+#pragma unroll 8
             for (int k = 0; k < d; ++k) acc += W[k * GS + g] * h[k];
-            for (int k = 0; k < d; ++k) acc += W[(d + k) * GS + g] * r[k];
-            gates[g] = acc;
+#pragma unroll 8
+            for (int k = 0; k < d; ++k) acc2 += W[(d + k) * GS + g] * r[k];
+            gates[g] = acc + acc2;
         }
         __syncthreads();
         // ---- LSTM cell (gate order i, f, g, o)
@@ -140,7 +163,7 @@ __global__ __launch_bounds__(256) void k_set2set_fwd(S2SFwdArgs a) {
         // ---- e = emb . h  (all n rows, padded rows included — set2set.py:50-51)
         float lmax = -INFINITY;
         for (int row = team; row < n; row += 16) {
-            const float* er = emb + (long)row * a.lde;
+            const float* er = emb + (long)row * lde;
             float s = 0.f;
             for (int k = tl; k < d; k += 16) s += er[k] * h[k];
             s = team16_sum(s);
@@ -165,8 +188,10 @@ __global__ __launch_bounds__(256) void k_set2set_fwd(S2SFwdArgs a) {
         for (int j0 = 0; j0 < d; j0 += 64) {
             const int j = j0 + (tid & 63), part = tid >> 6;
             float s = 0.f;
-            if (j < d)
-                for (int row = part; row < n; row += 4) s += al[row] * emb[(long)row * a.lde + j];
+            if (j < d) {
+#pragma unroll 8
+                for (int row = part; row < n; row += 4) s += al[row] * emb[(long)row * lde + j];
+            }
             rpart[part * 64 + (tid & 63)] = s;
             __syncthreads();
             if (part == 0 && j < d) r[j] = rpart[tid] + rpart[64 + tid] + rpart[128 + tid] + rpart[192 + tid];
@@ -196,6 +221,7 @@ struct S2SBwdArgs {
     float *DG, *DR, *DE, *DPRE;    // workspace outputs
     int n, d, GS;
     int w_in_lds;
+    int emb_in_lds;
 };
 
 __global__ __launch_bounds__(256) void k_set2set_bwd(S2SBwdArgs a) {
@@ -211,9 +237,15 @@ __global__ __launch_bounds__(256) void k_set2set_bwd(S2SBwdArgs a) {
     float* red = dg + 4 * d;         // [8]
     float* rpart = red + 8;          // [256]
     float* de = rpart + 256;         // [n]
+    float* lat = de + ((n + 15) & ~15);  // [n] attention weights a_t of the step being processed
+    float* le = lat + ((n + 15) & ~15);  // [n][d] when emb_in_lds
     const float* W = a.w_in_lds ? lw : a.wt;
     if (a.w_in_lds)
         for (int i = tid; i < 2 * d * GS; i += 256) lw[i] = a.wt[i];
+    if (a.emb_in_lds) {
+        const float* eg = a.emb + (long)b * n * a.lde;
+        for (int i = tid; i < n * d; i += 256) le[i] = eg[(long)(i / d) * a.lde + i % d];
+    }
     // ---- output layer: dpre = dout * (out > 0);  [dh, dr] = Wp^T dpre;  dc = 0
     for (int j = tid; j < d; j += 256) {
         const float o = a.out[(long)b * d + j];
@@ -229,48 +261,80 @@ __global__ __launch_bounds__(256) void k_set2set_bwd(S2SBwdArgs a) {
         if (k < d) dh[k] = s; else dr[k - d] = s;
     }
     __syncthreads();
-    const float* emb = a.emb + (long)b * n * a.lde;
+    const float* emb = a.emb_in_lds ? le : a.emb + (long)b * n * a.lde;
+    const int lde = a.emb_in_lds ? d : a.lde;
     const int tl = tid & 15, team = tid >> 4;
 
+    // The saved per-step state (a_t, gates, c_t, c_{t-1}) is read from global memory: fetched one step AHEAD into
+    // registers so the loads fly under the previous step instead of heading each step's critical path.
+    constexpr int APT = 4;                            // a_t rows per thread: n <= 1024 (checked by the launcher)
+    float at_n[APT], gn[6];
+    auto prefetch = [&](int t) {
+        const int tc = t < 0 ? 0 : t;                 // (the last prefetch is unused; keep the address valid)
+        const float* at = a.Aw + ((long)b * n + tc) * n;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) at_n[i] = at[min(tid + 256 * i, n - 1)];
+        const int j = min(tid, d - 1);
+        const float* gs = a.G + ((long)b * n + tc) * 4 * d;
+        gn[0] = gs[j]; gn[1] = gs[d + j]; gn[2] = gs[2 * d + j]; gn[3] = gs[3 * d + j];
+        gn[4] = a.Cs[((long)b * n + tc) * d + j];
+        gn[5] = tc > 0 ? a.Cs[((long)b * n + tc - 1) * d + j] : 0.f;
+    };
+    prefetch(n - 1);
     for (int t = n - 1; t >= 0; --t) {
-        const float* at = a.Aw + ((long)b * n + t) * n;
+        float at_c[APT], gc[6];
+#pragma unroll
+        for (int i = 0; i < APT; ++i) at_c[i] = at_n[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gc[i] = gn[i];
+#pragma unroll
+        for (int i = 0; i < APT; ++i)
+            if (tid + 256 * i < n) lat[tid + 256 * i] = at_c[i];
         // ---- r_t = sum a emb:  da = emb . dr ;  de = a * (da - sum a da)
         for (int j = tid; j < d; j += 256) a.DR[((long)b * n + t) * d + j] = dr[j];
+        __syncthreads();
+        prefetch(t - 1);
         float lsum = 0.f;
         for (int row = team; row < n; row += 16) {
-            const float* er = emb + (long)row * a.lde;
+            const float* er = emb + (long)row * lde;
             float s = 0.f;
             for (int k = tl; k < d; k += 16) s += er[k] * dr[k];
             s = team16_sum(s);
             if (tl == 0) {
                 de[row] = s;
-                lsum += at[row] * s;
+                lsum += lat[row] * s;
             }
         }
         const float sdot = block_sum(lsum, red);
-        for (int row = tid; row < n; row += 256) {
-            const float v = at[row] * (de[row] - sdot);
-            de[row] = v;
-            a.DE[((long)b * n + t) * n + row] = v;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int row = tid + 256 * i;
+            if (row < n) {
+                const float v = at_c[i] * (de[row] - sdot);
+                de[row] = v;
+                a.DE[((long)b * n + t) * n + row] = v;
+            }
         }
         __syncthreads();
         // ---- e = emb . h_t:  dh += sum_n de[n] emb[n]
         for (int j0 = 0; j0 < d; j0 += 64) {
             const int j = j0 + (tid & 63), part = tid >> 6;
             float s = 0.f;
-            if (j < d)
-                for (int row = part; row < n; row += 4) s += de[row] * emb[(long)row * a.lde + j];
+            if (j < d) {
+#pragma unroll 8
+                for (int row = part; row < n; row += 4) s += de[row] * emb[(long)row * lde + j];
+            }
             rpart[part * 64 + (tid & 63)] = s;
             __syncthreads();
             if (part == 0 && j < d) dh[j] += rpart[tid] + rpart[64 + tid] + rpart[128 + tid] + rpart[192 + tid];
             __syncthreads();
         }
         // ---- LSTM cell backward
-        for (int j = tid; j < d; j += 256) {
-            const float* gs = a.G + ((long)b * n + t) * 4 * d;
-            const float ig = gs[j], fg = gs[d + j], gg = gs[2 * d + j], og = gs[3 * d + j];
-            const float ct = a.Cs[((long)b * n + t) * d + j];
-            const float cp = t > 0 ? a.Cs[((long)b * n + t - 1) * d + j] : 0.f;
+        if (tid < d) {
+            const int j = tid;
+            const float ig = gc[0], fg = gc[1], gg = gc[2], og = gc[3];
+            const float ct = gc[4];
+            const float cp = gc[5];
             const float tc = tanhf(ct);
             const float dhj = dh[j];
             const float dct = dc[j] + dhj * og * (1.f - tc * tc);
@@ -286,20 +350,27 @@ __global__ __launch_bounds__(256) void k_set2set_bwd(S2SBwdArgs a) {
         __syncthreads();
         // ---- [dh_{t-1}, dr_{t-1}] = Wt dg   (h_{t-1} and r_{t-1} feed only this step's LSTM)
         for (int k = tid; k < 2 * d; k += 256) {
-            float s = 0.f;
+            float s = 0.f, s2 = 0.f;
             const float* wr = W + (long)k * GS;
-            for (int g = 0; g < 4 * d; ++g) s += wr[g] * dg[g];
+#pragma unroll 4
+            for (int g = 0; g < 2 * d; ++g) {
+                s += wr[g] * dg[g];
+                s2 += wr[2 * d + g] * dg[2 * d + g];
+            }
+            s += s2;
             if (k < d) dh[k] = s; else dr[k - d] = s;
         }
         __syncthreads();
     }
 }
 
-size_t s2s_dyn_lds(int n, int d, bool w_in_lds) {
+size_t s2s_dyn_lds(int n, int d, bool w_in_lds, bool emb_in_lds = false) {
     const size_t GS = 4 * d + 1;
-    return ((w_in_lds ? (size_t)2 * d * GS : 0) + 7 * d + 8 + 256 + n + 16) * sizeof(float);
+    return ((w_in_lds ? (size_t)2 * d * GS : 0) + 7 * d + 8 + 256 + 2 * ((n + 15) & ~15) + 16 +
+            (emb_in_lds ? (size_t)n * d : 0)) * sizeof(float);
 }
 bool s2s_w_fits(int n, int d) { return s2s_dyn_lds(n, d, true) <= 158 * 1024; }
+bool s2s_emb_fits(int n, int d) { return s2s_dyn_lds(n, d, s2s_w_fits(n, d), true) <= 158 * 1024; }
 
 }  // namespace
 
@@ -310,8 +381,8 @@ void set2set_fwd(Seq& q, const float* emb, int lde, const float* w_ih, const flo
     if (q.err) return;
     const S2SLayout L = s2s_layout(B, n, d);
     if (!q.ok()) return;
-    if (s2s_dyn_lds(n, d, false) > 158 * 1024) {
-        set_error("Set2Set: n=%d does not fit the per-step LDS buffers", n);
+    if (s2s_dyn_lds(n, d, false) > 158 * 1024 || d > 256 || n > 1024) {
+        set_error("Set2Set: n=%d / d=%d outside the persistent kernel's limits (n <= 1024, d <= 256)", n, d);
         q.err = DP_ERR_UNSUPPORTED;
         return;
     }
@@ -324,7 +395,8 @@ void set2set_fwd(Seq& q, const float* emb, int lde, const float* w_ih, const flo
     a.QP = sv + L.qp; a.H = sv + L.h; a.Cs = sv + L.c; a.G = sv + L.g; a.Aw = sv + L.a; a.QN = sv + L.qn;
     a.n = n; a.d = d; a.GS = L.GS;
     a.w_in_lds = s2s_w_fits(n, d) ? 1 : 0;
-    const size_t ldsb = s2s_dyn_lds(n, d, a.w_in_lds);
+    a.emb_in_lds = s2s_emb_fits(n, d) ? 1 : 0;
+    const size_t ldsb = s2s_dyn_lds(n, d, a.w_in_lds, a.emb_in_lds);
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_set2set_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -355,13 +427,14 @@ void set2set_bwd(Seq& q, const float* emb, int lde, const float* w_ih, const flo
     a.DG = DG; a.DR = DR; a.DE = DE; a.DPRE = DPRE;
     a.n = n; a.d = d; a.GS = L.GS;
     a.w_in_lds = s2s_w_fits(n, d) ? 1 : 0;
+    a.emb_in_lds = s2s_emb_fits(n, d) ? 1 : 0;
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_set2set_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL(k_set2set_bwd, dim3(B), dim3(256), s2s_dyn_lds(n, d, a.w_in_lds), q.stream, a);
+    hipLaunchKernelGGL(k_set2set_bwd, dim3(B), dim3(256), s2s_dyn_lds(n, d, a.w_in_lds, a.emb_in_lds), q.stream, a);
     q.check_launch("set2set_bwd");
     const float* QP = sv + L.qp;
     const float* QN = sv + L.qn;
