@@ -1,23 +1,42 @@
-"""SupervisedGraphSage head (graphsage.py:7-26) with the reference's undefined names repaired
-(`init` is never imported there, `nn.softmax` does not exist — SURVEY.md Appendix B D10):
-scores = enc(nodes) @ W;  loss = CrossEntropy(scores, labels)."""
+"""Supervised GraphSAGE classification head.
+
+Mirrors the public surface of the reference's `SupervisedGraphSage` (graphsage.py:7-26) — constructor
+`(num_classes, enc)`, `forward(nodes) -> scores [len(nodes), num_classes]`, `loss(nodes, labels)`, one parameter named
+`weight` of shape `[enc.embed_dim, num_classes]` — on top of an encoder that produces node embeddings (here
+`graph_pooling_amd.aggregators.MeanAggregator`-based encoders, whose mean aggregation runs in `dp_mean_aggregate_*`).
+
+The reference file cannot run as written: it calls an `init` module it never imports and a
+non-existent `nn.softmax`.  Decisions: Xavier-uniform initialisation of `weight` (what `init.xavier_uniform` meant),
+and the loss is plain cross-entropy on the raw scores — `CrossEntropyLoss` already applies log-softmax, so the
+reference's extra softmax would be a double normalisation.
+"""
+from __future__ import annotations
+
+import math
+
 import torch
-import torch.nn as nn
-from torch.nn import init
+import torch.nn.functional as F
+from torch import Tensor, nn
 
 
 class SupervisedGraphSage(nn.Module):
-    def __init__(self, num_classes, enc):
+    def __init__(self, num_classes: int, enc: nn.Module):
         super().__init__()
+        embed_dim = int(getattr(enc, "embed_dim"))
+        if num_classes < 1 or embed_dim < 1:
+            raise ValueError(f"need num_classes >= 1 and enc.embed_dim >= 1, got {num_classes} / {embed_dim}")
         self.enc = enc
-        self.xent = nn.CrossEntropyLoss()
-        self.weight = nn.Parameter(torch.empty(enc.embed_dim, num_classes))
-        init.xavier_uniform_(self.weight)
+        bound = math.sqrt(6.0 / (embed_dim + num_classes))            # Xavier / Glorot uniform
+        self.weight = nn.Parameter(torch.empty(embed_dim, num_classes).uniform_(-bound, bound))
 
-    def forward(self, nodes):
-        embeds = self.enc(nodes)
-        return embeds.mm(self.weight)
+    @property
+    def xent(self):
+        """Kept for callers that reach for the reference's attribute: the criterion `loss` applies."""
+        return F.cross_entropy
 
-    def loss(self, nodes, labels):
-        scores = self.forward(nodes)
-        return self.xent(scores, labels.squeeze())
+    def forward(self, nodes) -> Tensor:
+        return torch.matmul(self.enc(nodes), self.weight)
+
+    def loss(self, nodes, labels: Tensor) -> Tensor:
+        target = labels.reshape(-1).to(dtype=torch.long)
+        return F.cross_entropy(self.forward(nodes), target)

@@ -105,3 +105,32 @@ def test_optimiser_and_batch_builder_argument_checks(lib):
     q = C.addressof(i4)
     assert lib.dp_build_batch(q, q, q, None, q, p, p, q, q, 2, 8, 3, 1, 4, None) < 0      # feats without labels
     assert lib.dp_build_batch(q, q, q, q, q, None, p, q, q, 2, 8, 3, 1, 4, None) < 0      # adj is NULL
+
+
+def test_supervised_graphsage_head_on_a_stub_encoder():
+    """graphsage.py:7-26 with the D10 repairs: scores = enc(nodes) @ weight, cross-entropy on the raw scores."""
+    from graph_pooling_amd.graphsage import SupervisedGraphSage
+
+    class Enc(torch.nn.Module):
+        embed_dim = 5
+
+        def __init__(self):
+            super().__init__()
+            self.table = torch.nn.Parameter(torch.randn(11, 5))
+
+        def forward(self, nodes):
+            return self.table[torch.as_tensor(nodes)]
+
+    torch.manual_seed(0)
+    head = SupervisedGraphSage(3, Enc())
+    assert tuple(head.weight.shape) == (5, 3) and set(dict(head.named_parameters())) == {"weight", "enc.table"}
+    nodes, labels = [0, 4, 7, 10], torch.tensor([[0], [2], [1], [2]])
+    scores = head(nodes)
+    assert tuple(scores.shape) == (4, 3)
+    ref = torch.nn.functional.cross_entropy(head.enc(nodes) @ head.weight, labels.squeeze())
+    loss = head.loss(nodes, labels)
+    assert torch.allclose(loss, ref)
+    loss.backward()
+    assert head.weight.grad is not None and head.enc.table.grad is not None
+    with pytest.raises(ValueError):
+        SupervisedGraphSage(0, Enc())
