@@ -95,7 +95,7 @@ _PROTOS = {
     "dp_encoder_workspace_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "dp_encoder_forward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
     "dp_encoder_backward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
-    "dp_build_batch": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dp_build_batch": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dp_clip_adam_workspace_bytes": (_Z, []),
     "dp_clip_adam_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P, _P, _Z, _P]),
     "dp_loss_workspace_bytes": (_Z, [_I, _I, _I, _I]),

@@ -72,8 +72,20 @@ class EdgeListDataset:
 class DeviceBatchBuilder:
     _RING = 4          # pinned staging buffers in rotation (a buffer is reused only after its copy has completed)
 
-    def __init__(self, dataset: EdgeListDataset, max_nodes: int, feat_dim: int, device="cuda"):
+    _MODES = {"default": 0, "id": 1, "deg-num": 2, "deg": 3}
+
+    def __init__(self, dataset: EdgeListDataset, max_nodes: int, feat_dim: int, device="cuda",
+                 features: str = "default", assign_feat: str = "default"):
+        """`features` / `assign_feat` are the sampler's modes (graph_sampler.py:33-59, 85-87); `feat_dim` is the
+        width of the one-hot node labels.  'struct' (clustering coefficients) is host-only: tu_dataset.collate."""
+        if features not in self._MODES:
+            raise ValueError(f"feature mode {features!r} is not built on the device (default | id | deg-num | deg); "
+                             "use tu_dataset.collate for 'struct'")
+        if assign_feat not in ("default", "id"):
+            raise ValueError(f"unknown assign_feat {assign_feat!r} (default | id)")
         self.ds, self.N, self.F = dataset, int(max_nodes), int(feat_dim)
+        self.mode, self.assign_id = self._MODES[features], assign_feat == "id"
+        self.Fout = {0: self.F, 1: self.N, 2: 1, 3: 11 + self.F}[self.mode]
         self.device = torch.device(device)
         self._stage = [None] * self._RING       # (pinned int32 tensor, event)
         self._turn = 0
@@ -117,7 +129,7 @@ class DeviceBatchBuilder:
         if int(n.max()) > self.N:
             raise ValueError(f"a graph of the batch has {int(n.max())} nodes > max_nodes={self.N} "
                              "(the reference's loader drops such graphs, load_data.py:79)")
-        if len(lab) and (int(lab.min()) < 0 or int(lab.max()) >= self.F):
+        if self.mode in (0, 3) and len(lab) and (int(lab.min()) < 0 or int(lab.max()) >= self.F):
             raise ValueError(f"node label outside [0, {self.F})")
         dev = self.device
         parts = [src, dst, edge_ptr, lab, node_ptr]
@@ -125,16 +137,19 @@ class DeviceBatchBuilder:
         packed = self._to_device(parts)
         view = [packed[offs[i]:offs[i + 1]] for i in range(len(parts))]
         adj = torch.empty(B, self.N, self.N, device=dev, dtype=torch.float32)
-        feats = torch.empty(B, self.N, self.F, device=dev, dtype=torch.float32)
+        feats = torch.empty(B, self.N, self.Fout, device=dev, dtype=torch.float32)
+        assign = torch.empty(B, self.N, self.N + self.Fout, device=dev, dtype=torch.float32) if self.assign_id else None
+        degree = torch.empty(B * self.N, device=dev, dtype=torch.int32) if self.mode >= 2 else None
         nn_dev = torch.empty(B, device=dev, dtype=torch.int32)
-        errors = torch.zeros(1, device=dev, dtype=torch.int32)
+        errors = torch.empty(1, device=dev, dtype=torch.int32)
         _lib.require_gpu_tensor(adj, "adj")
         ptr = lambda t: t.data_ptr() if t.numel() else errors.data_ptr()          # noqa: E731  (never dereferenced)
         _lib.check(lib.dp_build_batch(ptr(view[0]), ptr(view[1]), view[2].data_ptr(), ptr(view[3]), view[4].data_ptr(),
-                                      adj.data_ptr(), feats.data_ptr(), nn_dev.data_ptr(), errors.data_ptr(), B, self.N,
-                                      self.F, 1, max_edges, _lib.current_stream()), "dp_build_batch")
+                                      adj.data_ptr(), feats.data_ptr(), _lib.ptr(assign), nn_dev.data_ptr(),
+                                      errors.data_ptr(), _lib.ptr(degree), B, self.N, self.F, self.mode, 1, max_edges,
+                                      _lib.current_stream()), "dp_build_batch")
         if check and int(errors.item()) != 0:
             raise RuntimeError(f"dp_build_batch skipped {int(errors.item())} out-of-range entries")
         label = torch.from_numpy(np.ascontiguousarray(glabel)).to(dev)
-        return {"adj": adj, "feats": feats, "assign_feats": feats, "label": label,
+        return {"adj": adj, "feats": feats, "assign_feats": assign if assign is not None else feats, "label": label,
                 "num_nodes": n.astype(np.int32), "num_nodes_device": nn_dev}

@@ -541,15 +541,21 @@ int dp_loss_backward(const float* prob, const long long* label, const float* S, 
 }
 
 int dp_build_batch(const int* edge_src, const int* edge_dst, const int* edge_ptr, const int* node_label,
-                   const int* node_ptr, float* adj, float* feats, int* num_nodes, int* errors, int B, int N, int F,
-                   int symmetric, int max_edges_per_graph, void* stream) {
+                   const int* node_ptr, float* adj, float* feats, float* assign_feats, int* num_nodes, int* errors,
+                   int* degree, int B, int N, int F, int feature_mode, int symmetric, int max_edges_per_graph,
+                   void* stream) {
     NOTNULL(edge_src); NOTNULL(edge_dst); NOTNULL(edge_ptr); NOTNULL(node_ptr); NOTNULL(adj); NOTNULL(num_nodes);
     NOTNULL(errors);
     NONNEG(B); NONNEG(N);
-    DP_CHECK_ARG(!feats || (node_label && F > 0), "one-hot features need node labels and F > 0");
+    DP_CHECK_ARG(feature_mode >= 0 && feature_mode <= 3, "feature_mode=%d (0 default, 1 id, 2 deg-num, 3 deg)",
+                 feature_mode);
+    const bool labels = feature_mode == 0 || feature_mode == 3;
+    DP_CHECK_ARG(!(feats || assign_feats) || !labels || (node_label && F > 0),
+                 "label-based features need node labels and F > 0");
+    DP_CHECK_ARG(feature_mode < 2 || degree, "deg / deg-num features need the degree workspace (B*N ints)");
     Seq q(STREAM(stream), nullptr, 0);
-    build_batch(q, edge_src, edge_dst, edge_ptr, node_label, node_ptr, adj, feats, num_nodes, errors, B, N, F, symmetric,
-                max_edges_per_graph);
+    build_batch(q, edge_src, edge_dst, edge_ptr, node_label, node_ptr, adj, feats, assign_feats, num_nodes, errors,
+                degree, B, N, F, feature_mode, symmetric, max_edges_per_graph);
     return q.err;
 }
 

@@ -11,7 +11,7 @@ namespace dp {
 
 __global__ __launch_bounds__(256) void k_scatter_edges(const int* src, const int* dst, const int* edge_ptr,
                                                        const int* node_ptr, float* adj, int B, int N, int symmetric,
-                                                       int* errors) {
+                                                       int* errors, int* degree) {
     const int b = blockIdx.y;
     const int e0 = edge_ptr[b], e1 = edge_ptr[b + 1];
     const int nb = min(node_ptr[b + 1] - node_ptr[b], N);
@@ -25,43 +25,81 @@ __global__ __launch_bounds__(256) void k_scatter_edges(const int* src, const int
         }
         A[(long)s * N + d] = 1.f;                 // duplicates write the same value: no atomics needed
         if (symmetric) A[(long)d * N + s] = 1.f;
+        if (degree) {                             // node degrees for the deg / deg-num feature modes (the edge list
+            atomicAdd(degree + (long)b * N + s, 1);   // holds every undirected edge once, or both directions when
+            if (symmetric) atomicAdd(degree + (long)b * N + d, 1);   // symmetric == 0)
+        }
     }
     if (bad) atomicAdd(errors, bad);
 }
 
-__global__ __launch_bounds__(256) void k_onehot_nodes(const int* label, const int* node_ptr, float* feats,
-                                                      int* num_nodes, int B, int N, int F, int* errors) {
+// Node features in the sampler's modes (graph_sampler.py:33-59, 85-87); feats / assign are zero-filled beforehand.
+//   0 default: one-hot node label            1 id: identity of size N (padded rows too)
+//   2 deg-num: the degree, one column        3 deg: one-hot degree capped at 10, then the one-hot node label
+// assign != null additionally writes [identity(N) | feats] (assign_feat='id').
+__global__ __launch_bounds__(256) void k_node_features(const int* label, const int* node_ptr, const int* degree,
+                                                       float* feats, float* assign, int* num_nodes, int B, int N, int F,
+                                                       int Fout, int mode, int* errors) {
     const int b = blockIdx.y;
     const int p0 = node_ptr[b], n = node_ptr[b + 1] - p0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         num_nodes[b] = min(n, N);
         if (n > N) atomicAdd(errors, n - N);
     }
-    if (!feats) return;
-    float* Fb = feats + (long)b * N * F;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < min(n, N); i += gridDim.x * 256) {
-        const int l = label[p0 + i];
-        if (l < 0 || l >= F) atomicAdd(errors, 1);
-        else Fb[(long)i * F + l] = 1.f;
+    const int nb = min(n, N);
+    const int la = N + Fout;                           // row width of the assign features
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        float* f = feats ? feats + ((long)b * N + i) * Fout : nullptr;
+        float* as = assign ? assign + ((long)b * N + i) * la : nullptr;
+        if (as) as[i] = 1.f;
+        auto put = [&](int c, float v) {
+            if (f) f[c] = v;
+            if (as) as[N + c] = v;
+        };
+        if (mode == 1) {
+            put(i, 1.f);
+            continue;
+        }
+        if (i >= nb) continue;
+        int l = -1;
+        if (mode == 0 || mode == 3) {
+            l = label[p0 + i];
+            if (l < 0 || l >= F) {
+                atomicAdd(errors, 1);
+                l = -1;
+            }
+        }
+        if (mode == 0) {
+            if (l >= 0) put(l, 1.f);
+        } else if (mode == 2) {
+            put(0, (float)degree[(long)b * N + i]);
+        } else {
+            put(min(degree[(long)b * N + i], 10), 1.f);
+            if (l >= 0) put(11 + l, 1.f);
+        }
     }
 }
 
 void build_batch(Seq& q, const int* src, const int* dst, const int* edge_ptr, const int* label, const int* node_ptr,
-                 float* adj, float* feats, int* num_nodes, int* errors, int B, int N, int F, int symmetric,
-                 int max_edges_per_graph) {
+                 float* adj, float* feats, float* assign, int* num_nodes, int* errors, int* degree, int B, int N, int F,
+                 int mode, int symmetric, int max_edges_per_graph) {
     if (!q.ok() || B <= 0) return;
+    const int Fout = mode == 0 ? F : (mode == 1 ? N : (mode == 2 ? 1 : 11 + F));
     zero_fill(q, adj, (size_t)B * N * N * sizeof(float));
-    if (feats) zero_fill(q, feats, (size_t)B * N * F * sizeof(float));
+    if (feats) zero_fill(q, feats, (size_t)B * N * Fout * sizeof(float));
+    if (assign) zero_fill(q, assign, (size_t)B * N * (N + Fout) * sizeof(float));
+    const bool need_deg = mode == 2 || mode == 3;
+    if (need_deg) zero_fill(q, degree, (size_t)B * N * sizeof(int));
     zero_small(q, errors, sizeof(int));
     int gx = (max_edges_per_graph + 255) / 256;
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
     hipLaunchKernelGGL(k_scatter_edges, dim3(gx, B), dim3(256), 0, q.stream, src, dst, edge_ptr, node_ptr, adj, B, N,
-                       symmetric, errors);
+                       symmetric, errors, need_deg ? degree : (int*)nullptr);
     q.check_launch("scatter_edges");
     int gn = (N + 255) / 256;
-    hipLaunchKernelGGL(k_onehot_nodes, dim3(gn, B), dim3(256), 0, q.stream, label, node_ptr, feats, num_nodes, B, N, F,
-                       errors);
-    q.check_launch("onehot_nodes");
+    hipLaunchKernelGGL(k_node_features, dim3(gn, B), dim3(256), 0, q.stream, label, node_ptr, degree, feats, assign,
+                       num_nodes, B, N, F, Fout, mode, errors);
+    q.check_launch("node_features");
 }
 
 }  // namespace dp

@@ -245,8 +245,8 @@ void head_bwd(Seq& q, const HeadBwdArgs& a);
 
 // (dp_batch.hip)
 void build_batch(Seq& q, const int* src, const int* dst, const int* edge_ptr, const int* label, const int* node_ptr,
-                 float* adj, float* feats, int* num_nodes, int* errors, int B, int N, int F, int symmetric,
-                 int max_edges_per_graph);
+                 float* adj, float* feats, float* assign, int* num_nodes, int* errors, int* degree, int B, int N, int F,
+                 int mode, int symmetric, int max_edges_per_graph);
 
 // (dp_optim.hip)
 void clip_adam_step(Seq& q, float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_norm,

@@ -262,14 +262,20 @@ int dp_loss_backward(const float* prob, const long long* label, const float* S, 
 
 /* ------------------------------------------------------------------ N1  on-device batch builder
  * Replaces GraphSampler.__getitem__ + collate + H2D of the dense batch (graph_sampler.py:97-109, train.py:197-201):
- * the host ships the batch's edge lists, the device writes adj [B,N,N] (0/1, zero padded), one-hot feats [B,N,F]
- * (NULL: skip) and num_nodes [B].  Graph b owns edges [edge_ptr[b], edge_ptr[b+1]) with node ids local to the
- * graph, and node labels label[node_ptr[b] .. node_ptr[b+1]).  symmetric != 0 also sets adj[d][s] (undirected
- * edge lists that store each edge once).  errors: device int, receives the number of skipped out-of-range
- * entries (0 = clean batch).  max_edges_per_graph only sizes the launch. */
+ * the host ships the batch's edge lists, the device writes adj [B,N,N] (0/1, zero padded), the node features
+ * feats [B,N,Fout] (NULL: skip) and num_nodes [B].  Graph b owns edges [edge_ptr[b], edge_ptr[b+1]) with node ids
+ * local to the graph, and node labels label[node_ptr[b] .. node_ptr[b+1]).  symmetric != 0 also sets adj[d][s]
+ * (undirected edge lists that store each edge once).
+ * feature_mode (graph_sampler.py:33-59): 0 one-hot node label (Fout = F), 1 identity (Fout = N), 2 degree as one
+ * column (Fout = 1), 3 one-hot degree capped at 10 then the one-hot label (Fout = 11 + F); modes 2 and 3 need the
+ * `degree` workspace (B*N ints).  assign_feats [B,N,N+Fout] (NULL: skip) = [identity | feats], the sampler's
+ * assign_feat='id' (graph_sampler.py:85-87).
+ * errors: device int, receives the number of skipped out-of-range entries (0 = clean batch).
+ * max_edges_per_graph only sizes the launch. */
 int dp_build_batch(const int* edge_src, const int* edge_dst, const int* edge_ptr, const int* node_label,
-                   const int* node_ptr, float* adj, float* feats, int* num_nodes, int* errors, int B, int N, int F,
-                   int symmetric, int max_edges_per_graph, void* stream);
+                   const int* node_ptr, float* adj, float* feats, float* assign_feats, int* num_nodes, int* errors,
+                   int* degree, int B, int N, int F, int feature_mode, int symmetric, int max_edges_per_graph,
+                   void* stream);
 
 /* ------------------------------------------------------------------ N2  fused gradient clip + Adam step
  * train.py:209-210 on top of the Adam of train.py:173, over the flat fp32 parameter / gradient buffers (n floats):

@@ -62,6 +62,30 @@ def test_device_batch_is_bit_identical_to_host_collate(count, n_max, F_, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("features,assign_feat", [("id", "default"), ("deg-num", "default"), ("deg", "default"),
+                                                  ("default", "id"), ("deg", "id")])
+def test_device_feature_modes_match_host_collate(features, assign_feat):
+    count, n_max, F_, N = 9, 40, 4, 48
+    graphs = _random_graphs(count, n_max, F_, seed=21)
+    hub = np.zeros((20, 20), dtype=np.float32)                 # a degree above the one-hot cap of 10
+    hub[0, 1:] = hub[1:, 0] = 1
+    graphs.append(TUGraph(hub, np.zeros(20, dtype=np.int64), 1))
+    ds = EdgeListDataset.from_tu_graphs(graphs)
+    ref = collate(graphs, N, F_, features=features, assign_feat=assign_feat)
+    got = DeviceBatchBuilder(ds, N, F_, "cuda", features=features, assign_feat=assign_feat).build(range(len(graphs)))
+    assert torch.equal(got["adj"].cpu(), torch.from_numpy(ref["adj"]))
+    assert torch.equal(got["feats"].cpu(), torch.from_numpy(ref["feats"]))
+    assert torch.equal(got["assign_feats"].cpu(), torch.from_numpy(ref["assign_feats"]))
+    np.testing.assert_array_equal(got["num_nodes"], ref["num_nodes"])
+
+
+def test_struct_mode_is_host_only():
+    ds = EdgeListDataset.from_tu_graphs(_random_graphs(2, 8, 3, seed=1))
+    with pytest.raises(ValueError):
+        DeviceBatchBuilder(ds, 8, 3, "cpu", features="struct")
+
+
+@pytest.mark.gpu
 def test_device_built_batch_drives_the_encoder_like_the_host_batch():
     from graph_pooling_amd.encoders import SoftPoolingGcnEncoder
     graphs = _random_graphs(6, 40, 4, seed=9)

@@ -103,8 +103,10 @@ def test_optimiser_and_batch_builder_argument_checks(lib):
     assert lib.dp_clip_adam_workspace_bytes() >= 1024
     i4 = (C.c_int * 4)()
     q = C.addressof(i4)
-    assert lib.dp_build_batch(q, q, q, None, q, p, p, q, q, 2, 8, 3, 1, 4, None) < 0      # feats without labels
-    assert lib.dp_build_batch(q, q, q, q, q, None, p, q, q, 2, 8, 3, 1, 4, None) < 0      # adj is NULL
+    assert lib.dp_build_batch(q, q, q, None, q, p, p, None, q, q, None, 2, 8, 3, 0, 1, 4, None) < 0   # feats, no labels
+    assert lib.dp_build_batch(q, q, q, q, q, None, p, None, q, q, None, 2, 8, 3, 0, 1, 4, None) < 0   # adj is NULL
+    assert lib.dp_build_batch(q, q, q, q, q, p, p, None, q, q, None, 2, 8, 3, 3, 1, 4, None) < 0      # deg mode, no ws
+    assert lib.dp_build_batch(q, q, q, q, q, p, p, None, q, q, q, 2, 8, 3, 7, 1, 4, None) < 0         # unknown mode
 
 
 def test_supervised_graphsage_head_on_a_stub_encoder():
