@@ -91,13 +91,16 @@ __global__ __launch_bounds__(1024) void k_small_gcn_fwd(SmallFwdArgs a) {
     float* U = P + n * dout;           // [n][dout]
     float* mu = U + n * dout;          // [n]
     float* rs = mu + n;                // [n]
-    float* PP = rs + n;                // [B][n][2] staged BN partials of the previous layer
+    float* BI = rs + n;                // [dout] bias (zeros without one)
+    float* PP = BI + dout;             // [B][n][2] staged BN partials of the previous layer
     const int tl = tid & 15, team = tid >> 4;
     const int NT = blockDim.x, NTEAMS = blockDim.x >> 4;
     const bool bnprev = !a.x0 && a.part_prev;
 
     for (int i = tid; i < n * n; i += NT) A[i] = a.adj[(long)b * n * n + i];
     for (int i = tid; i < din * dout; i += NT) W[i] = a.W[i];
+    for (int i = tid; i < dout; i += NT) BI[i] = a.bias ? a.bias[i] : 0.f;   // (a global load per output element
+                                                                              //  in the epilogue otherwise)
     if (a.x0) {
         for (int r = team; r < n; r += NTEAMS)
             for (int k = tl; k < din; k += 16) X[r * din + k] = a.x0[((long)b * n + r) * a.ldx0 + k];
@@ -145,8 +148,7 @@ __global__ __launch_bounds__(1024) void k_small_gcn_fwd(SmallFwdArgs a) {
     // U = A P (+ P) + bias
     lds_mma<false, false>(A, n, P, dout, n, dout, n, [&](int r, int c, float v) {
         if (a.add_self) v += P[r * dout + c];
-        if (a.bias) v += a.bias[c];
-        U[r * dout + c] = v;
+        U[r * dout + c] = v + BI[c];
     });
     __syncthreads();
     // l2-normalise rows, BN partials of relu(y)
@@ -220,14 +222,21 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
     float* IV = DX + n * din;          // [n] 1/||u||
     float* M0 = IV + n;                // [n]
     float* M1 = M0 + n;                // [n]
-    float* PP = M1 + n;                // [B][n][2] staged BN-backward partials
+    float* RS = M1 + n;                // [n] BN rstd of this layer
+    float* DA = RS + n;                // [n][n] running dA' (when the level's adjacency gradient is wanted)
+    float* PP = DA + (a.dadj ? n * n : 0);   // [B][n][2] staged BN-backward partials
     const int tl = tid & 15, team = tid >> 4;
     const int NT = blockDim.x, NTEAMS = blockDim.x >> 4;
     float* dWb = a.dW + (long)b * a.slab_stride;
     float* dbb = a.db ? a.db + (long)b * a.slab_stride : nullptr;
 
-    // ---- one burst: everything this layer reads from global
+    // ---- one burst: everything this layer reads from global (a load issued later sits alone on the critical path:
+    //      the BN rstd and the read half of the dA' += update used to)
     for (int i = tid; i < n * n; i += NT) A[i] = a.adj[(long)b * n * n + i];
+    if (a.dadj)
+        for (int i = tid; i < n * n; i += NT) DA[i] = a.dadj[(long)b * n * n + i];
+    if (a.has_bn)
+        for (int i = tid; i < n; i += NT) RS[i] = a.stats[i * 2 + 1];
     for (int i = tid; i < din * dout; i += NT) W[i] = a.W[i];
     for (int r = team; r < n; r += NTEAMS) {
         const long row = (long)b * n + r;
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
     }
     // ---- dU = normalise^T relu^T bn^T dx (in place over the staged dx), one team per row
     for (int r = team; r < n; r += NTEAMS) {
-        const float rstd = a.has_bn ? a.stats[r * 2 + 1] : 1.f;
+        const float rstd = a.has_bn ? RS[r] : 1.f;
         const float m0 = a.has_bn ? M0[r] : 0.f, m1 = a.has_bn ? M1[r] : 0.f;
         const float inv = IV[r];
         const bool project = inv < 1.0f / SM_L2_EPS;
@@ -284,6 +293,7 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
     if (dbb)
         for (int c = tid; c < dout; c += NT) {
             float s = 0.f;
+#pragma unroll 8
             for (int r = 0; r < n; ++r) s += dU[r * dout + c];
             dbb[c] = s;
         }
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
     // ---- dA += dU P^T
     if (a.dadj)
         lds_mma<false, true>(dU, dout, P, dout, n, n, dout, [&](int r, int m, float v) {
-            a.dadj[(long)b * n * n + r * n + m] += v;
+            a.dadj[(long)b * n * n + r * n + m] = DA[r * n + m] + v;
         });
     // ---- BN-backward partials of layer l-1: (sum_k dX[r][k], sum_k dX[r][k] xhat[r][k]); xhat_{l-1} = X
     if (a.part2_prev) {
@@ -328,10 +338,11 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
 }
 
 size_t small_lds_floats_fwd(int B, int n, int din, int dout) {
-    return (size_t)n * n + (size_t)n * din + (size_t)din * dout + 2 * (size_t)n * dout + 2 * n + (size_t)B * n * 2 + 16;
+    return (size_t)n * n + (size_t)n * din + (size_t)din * dout + 2 * (size_t)n * dout + 2 * n + dout +
+           (size_t)B * n * 2 + 16;
 }
 size_t small_lds_floats_bwd(int B, int n, int din, int dout) {
-    return (size_t)n * n + 2 * (size_t)n * din + (size_t)din * dout + 4 * (size_t)n * dout + 3 * n +
+    return 2 * (size_t)n * n + 2 * (size_t)n * din + (size_t)din * dout + 4 * (size_t)n * dout + 4 * n +
            (size_t)B * n * 2 + 16;
 }
 
