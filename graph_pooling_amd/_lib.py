@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiffpool_hip.so")
+LIB_PATH = os.environ.get("DP_LIB") or os.path.join(_HERE, "libdiffpool_hip.so")   # DP_LIB: a diagnostic build
 
 DP_MAX_LAYERS = 8
 DP_MAX_LEVELS = 4

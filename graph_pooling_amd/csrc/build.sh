@@ -3,17 +3,20 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libdiffpool_hip.so
+BUILD=build
+# DP_STAMP=1: diagnostic library with in-kernel phase stamps (never the product; load it with DP_LIB=<path>)
+if [ "${DP_STAMP:-0}" = "1" ]; then OUT=../libdiffpool_hip_stamp.so; BUILD=build_stamp; EXTRA="-DDP_STAMP"; else EXTRA=""; fi
 SRCS="dp_api.hip dp_gemm.hip dp_rowops.hip dp_linkpred.hip dp_model.hip dp_set2set.hip dp_meanagg.hip dp_agg.hip dp_small.hip dp_head.hip dp_optim.hip dp_batch.hip"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fvisibility=hidden"
-mkdir -p build
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fvisibility=hidden $EXTRA"
+mkdir -p $BUILD
 pids=()
 for s in $SRCS; do
-  o=build/${s%.hip}.o
+  o=$BUILD/${s%.hip}.o
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ dp_common.h -nt "$o" ] || [ ../../include/diffpool_hip.h -nt "$o" ]; then
     hipcc $FLAGS -c "$s" -o "$o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/*.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $BUILD/*.o
 echo "built $(realpath $OUT)"

@@ -14,6 +14,20 @@ namespace dp {
 #define SM_L2_EPS 1e-12f
 #define SM_BN_EPS 1e-5f
 
+#ifdef DP_STAMP
+// Diagnostic build only (csrc/build.sh with DP_STAMP=1 writes a separate library): shader-clock stamps of the phases of
+// workgroup 0, read back with dp_debug_stamps().  No stamp executes in the product build.
+__device__ unsigned long long g_small_stamps[2][32];
+#define SM_STAMP(k, i)                                                                       \
+    do {                                                                                     \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_small_stamps[k][i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define SM_STAMP(k, i) \
+    do {               \
+    } while (0)
+#endif
+
 namespace {
 
 __device__ inline float sm_team_sum(float v) {
@@ -26,19 +40,56 @@ __device__ inline float sm_team_sum(float v) {
 
 typedef float sm_f32x4 __attribute__((ext_vector_type(4)));
 
+// Bulk staging by LDS-DMA: dst[e] <- *src_of(e) for e < count, 64 dwords per wave instruction, no register round
+// trip; every request of every region is in flight before the single barrier that follows (whose fence drains
+// vmcnt).  The LDS destination is wave-uniform (M0) + 4 * lane.
+// In-kernel stamps (DP_STAMP build, tools/small_kernel_stamps.py) put the opening burst at ~10k of the backward
+// kernel's ~29k cycles and ~7.5k of the forward's ~15k whichever way it is written — plain load/store loops, this
+// DMA form, or registers with all loads issued first: one workgroup pulls ~180 KB through ONE CU's vector-memory
+// path, and 16 waves issuing DMAs at once pay ~400 cycles per instruction.  It is the structural floor of the
+// one-workgroup-per-graph design, not a scheduling accident.
+// e / d for e < 2^16, d <= 2^15 with a host-made reciprocal (a runtime integer division is ~40 VALU instructions, and
+// the staging issues one per element: it was the larger half of the staging time)
+struct SmDiv {
+    unsigned magic;
+    int d;
+    __device__ inline int quot(int e) const {
+        return d == 1 ? e : (int)(((unsigned long long)(unsigned)e * magic) >> 32);    // (2^32 / 1 + 1 does not fit)
+    }
+    __device__ inline int rem(int e) const { return e - quot(e) * d; }
+};
+static SmDiv sm_div(int d) { return SmDiv{(unsigned)(0x100000000ull / (unsigned)d + 1), d}; }
+
+template <typename SrcFn>
+__device__ inline void sm_dma(float* dst, int count, SrcFn src_of) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    for (int c0 = wave * 64; c0 < count; c0 += nw * 64) {
+        const int e = c0 + lane;
+        if (e < count)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_of(e),
+                                             (__attribute__((address_space(3))) void*)(dst + c0), 4, 0, 0);
+    }
+}
+
 // C[M x N] = op(A)[M x K] · op(B)[K x N] with both operands in LDS, on the fp32 MFMA (16x16x4), tiles dealt
 // round-robin to the workgroup's waves.  Reads outside the logical matrices return 0, so nothing needs
 // padding.  `store(i, j, v)` receives every in-range result element.
 template <bool TA, bool TB, typename Store>
-__device__ inline void lds_mma(const float* A, int lda, const float* B, int ldb, int M, int N, int K, Store store) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+__device__ inline void lds_mma(const float* A, int lda, const float* B, int ldb, int M, int N, int K, Store store,
+                               int wave_shift = 0) {
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    // `wave_shift` rotates the tile -> wave assignment so that two independent products issued back to back (8 tiles
+    // each at the DD shape, 16 waves) run side by side instead of both landing on waves 0-7
+    const int wave = ((threadIdx.x >> 6) + nwaves - wave_shift % nwaves) % nwaves;
     const int l15 = lane & 15, kq = lane >> 4;
     const int tm = (M + 15) / 16, tn = (N + 15) / 16;
     for (int t = wave; t < tm * tn; t += nwaves) {
         const int i = (t / tn) * 16 + l15, j = (t % tn) * 16 + l15;
         sm_f32x4 acc = (sm_f32x4){0.f, 0.f, 0.f, 0.f};
         // unconditional LDS reads on clamped indices + a select: a branch around each read makes the compiler wait
-        // for every one of them in turn (one wave per SIMD per tile here: nothing else hides that latency)
+        // for every one of them in turn.  (Reading 16 steps' fragments into registers first and then issuing the
+        // MFMAs back to back was tried: slower, 3.1k against 2.1k cycles per tile.)
         const int ic = min(i, M - 1), jc = min(j, N - 1);
         const bool iok = i < M, jok = j < N;
 #pragma unroll 8
@@ -76,6 +127,7 @@ struct SmallFwdArgs {
     float* part;           // [B, n, 2] out or null
     int B, n, din, dout;
     int add_self, stats;
+    SmDiv qdin;
 };
 
 // Every global input is staged into LDS in ONE burst (one round of global latency); all phases after the
@@ -97,18 +149,17 @@ __global__ __launch_bounds__(1024) void k_small_gcn_fwd(SmallFwdArgs a) {
     const int NT = blockDim.x, NTEAMS = blockDim.x >> 4;
     const bool bnprev = !a.x0 && a.part_prev;
 
-    for (int i = tid; i < n * n; i += NT) A[i] = a.adj[(long)b * n * n + i];
-    for (int i = tid; i < din * dout; i += NT) W[i] = a.W[i];
-    for (int i = tid; i < dout; i += NT) BI[i] = a.bias ? a.bias[i] : 0.f;   // (a global load per output element
-                                                                              //  in the epilogue otherwise)
-    if (a.x0) {
-        for (int r = team; r < n; r += NTEAMS)
-            for (int k = tl; k < din; k += 16) X[r * din + k] = a.x0[((long)b * n + r) * a.ldx0 + k];
-    } else {
-        for (int r = team; r < n; r += NTEAMS)
-            for (int k = tl; k < din; k += 16) X[r * din + k] = a.yprev[((long)b * n + r) * a.ldyp + k];
-        if (bnprev)
-            for (int i = tid; i < a.B * n * 2; i += NT) PP[i] = a.part_prev[i];
+    SM_STAMP(0, 0);
+    sm_dma(A, n * n, [&](int e) { return a.adj + (long)b * n * n + e; });
+    sm_dma(W, din * dout, [&](int e) { return a.W + e; });
+    if (a.bias) sm_dma(BI, dout, [&](int e) { return a.bias + e; });
+    else
+        for (int i = tid; i < dout; i += NT) BI[i] = 0.f;
+    {
+        const float* xsrc = a.x0 ? a.x0 : a.yprev;
+        const int ldx = a.x0 ? a.ldx0 : a.ldyp;
+        sm_dma(X, n * din, [&](int e) { return xsrc + ((long)b * n + a.qdin.quot(e)) * ldx + a.qdin.rem(e); });
+        if (bnprev) sm_dma(PP, a.B * n * 2, [&](int e) { return a.part_prev + e; });
     }
     __syncthreads();
     if (!a.x0) {
@@ -117,9 +168,11 @@ __global__ __launch_bounds__(1024) void k_small_gcn_fwd(SmallFwdArgs a) {
             float m = 0.f, rstd = 1.f;
             if (bnprev) {
                 float sm = 0.f;
+#pragma unroll 4
                 for (int bb = 0; bb < a.B; ++bb) sm += PP[(bb * n + r) * 2];
                 m = sm / (float)a.B;
                 float s2 = 0.f;
+#pragma unroll 4
                 for (int bb = 0; bb < a.B; ++bb) {
                     const float d = PP[(bb * n + r) * 2] - m;
                     s2 += PP[(bb * n + r) * 2 + 1] + (float)din * d * d;
@@ -142,15 +195,18 @@ __global__ __launch_bounds__(1024) void k_small_gcn_fwd(SmallFwdArgs a) {
             }
         __syncthreads();
     }
+    SM_STAMP(0, 1);
     // P = X W
     lds_mma<false, false>(X, din, W, dout, n, dout, din, [&](int r, int c, float v) { P[r * dout + c] = v; });
     __syncthreads();
+    SM_STAMP(0, 2);
     // U = A P (+ P) + bias
     lds_mma<false, false>(A, n, P, dout, n, dout, n, [&](int r, int c, float v) {
         if (a.add_self) v += P[r * dout + c];
         U[r * dout + c] = v + BI[c];
     });
     __syncthreads();
+    SM_STAMP(0, 3);
     // l2-normalise rows, BN partials of relu(y)
     for (int r = team; r < n; r += NTEAMS) {
         const long row = (long)b * n + r;
@@ -180,6 +236,7 @@ __global__ __launch_bounds__(1024) void k_small_gcn_fwd(SmallFwdArgs a) {
             }
         }
     }
+    SM_STAMP(0, 4);
 }
 
 struct SmallBwdArgs {
@@ -205,6 +262,7 @@ struct SmallBwdArgs {
     long slab_stride;
     int B, n, din, dout;
     int add_self, has_bn, has_relu;
+    SmDiv qdin, qdout;
 };
 
 __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
@@ -222,7 +280,8 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
     float* IV = DX + n * din;          // [n] 1/||u||
     float* M0 = IV + n;                // [n]
     float* M1 = M0 + n;                // [n]
-    float* RS = M1 + n;                // [n] BN rstd of this layer
+    float* DB = M1 + n;                // [dout] column sums of dU (bias gradient), LDS atomics
+    float* RS = DB + dout;             // [n] BN rstd of this layer
     float* DA = RS + n;                // [n][n] running dA' (when the level's adjacency gradient is wanted)
     float* PP = DA + (a.dadj ? n * n : 0);   // [B][n][2] staged BN-backward partials
     const int tl = tid & 15, team = tid >> 4;
@@ -230,33 +289,29 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
     float* dWb = a.dW + (long)b * a.slab_stride;
     float* dbb = a.db ? a.db + (long)b * a.slab_stride : nullptr;
 
-    // ---- one burst: everything this layer reads from global (a load issued later sits alone on the critical path:
-    //      the BN rstd and the read half of the dA' += update used to)
-    for (int i = tid; i < n * n; i += NT) A[i] = a.adj[(long)b * n * n + i];
-    if (a.dadj)
-        for (int i = tid; i < n * n; i += NT) DA[i] = a.dadj[(long)b * n * n + i];
+    SM_STAMP(1, 0);
+    // ---- one burst: everything this layer reads from global, all by LDS-DMA (see sm_dma)
+    sm_dma(A, n * n, [&](int e) { return a.adj + (long)b * n * n + e; });
+    if (a.dadj) sm_dma(DA, n * n, [&](int e) { return a.dadj + (long)b * n * n + e; });
+    if (a.has_bn) sm_dma(RS, n, [&](int e) { return a.stats + e * 2 + 1; });
+    sm_dma(W, din * dout, [&](int e) { return a.W + e; });
+    sm_dma(X, n * din, [&](int e) { return a.xin + ((long)b * n + a.qdin.quot(e)) * a.ldxin + a.qdin.rem(e); });
+    if (a.dxin)
+        sm_dma(DX, n * din, [&](int e) { return a.dxin + ((long)b * n + a.qdin.quot(e)) * a.lddxin + a.qdin.rem(e); });
+    sm_dma(dU, n * dout, [&](int e) { return a.dx + ((long)b * n + a.qdout.quot(e)) * a.lddx + a.qdout.rem(e); });
+    sm_dma(P, n * dout, [&](int e) { return a.y + ((long)b * n + a.qdout.quot(e)) * a.ldy + a.qdout.rem(e); });
     if (a.has_bn)
-        for (int i = tid; i < n; i += NT) RS[i] = a.stats[i * 2 + 1];
-    for (int i = tid; i < din * dout; i += NT) W[i] = a.W[i];
-    for (int r = team; r < n; r += NTEAMS) {
-        const long row = (long)b * n + r;
-        for (int k = tl; k < din; k += 16) {
-            X[r * din + k] = a.xin[row * a.ldxin + k];
-            if (a.dxin) DX[r * din + k] = a.dxin[row * a.lddxin + k];
-        }
-        for (int c = tl; c < dout; c += 16) {
-            dU[r * dout + c] = a.dx[row * a.lddx + c];
-            P[r * dout + c] = a.y[row * a.ldy + c];
-            if (a.has_bn) XH[r * dout + c] = a.xhat[row * a.ldxh + c];
-        }
-        if (tl == 0) IV[r] = a.invn[row];
-    }
-    if (a.has_bn)
-        for (int i = tid; i < a.B * n * 2; i += NT) PP[i] = a.part2[i];
+        sm_dma(XH, n * dout, [&](int e) { return a.xhat + ((long)b * n + a.qdout.quot(e)) * a.ldxh + a.qdout.rem(e); });
+    sm_dma(IV, n, [&](int e) { return a.invn + (long)b * n + e; });
+    if (a.has_bn) sm_dma(PP, a.B * n * 2, [&](int e) { return a.part2 + e; });
+    for (int i = tid; i < dout; i += NT) DB[i] = 0.f;
+    SM_STAMP(1, 8);
     __syncthreads();
+    SM_STAMP(1, 9);
     if (a.has_bn) {
         for (int r = tid; r < n; r += NT) {
             float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
             for (int bb = 0; bb < a.B; ++bb) {
                 s0 += PP[(bb * n + r) * 2];
                 s1 += PP[(bb * n + r) * 2 + 1];
@@ -267,8 +322,12 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
         }
         __syncthreads();
     }
+    SM_STAMP(1, 1);
     // ---- dU = normalise^T relu^T bn^T dx (in place over the staged dx), one team per row
-    for (int r = team; r < n; r += NTEAMS) {
+    // (uniform trip count: the bias-gradient column sums below reduce ACROSS the four row teams of a wave)
+    for (int r0 = 0; r0 < n; r0 += NTEAMS) {
+        const int r = min(r0 + team, n - 1);
+        const bool valid = r0 + team < n;
         const float rstd = a.has_bn ? RS[r] : 1.f;
         const float m0 = a.has_bn ? M0[r] : 0.f, m1 = a.has_bn ? M1[r] : 0.f;
         const float inv = IV[r];
@@ -279,32 +338,45 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
             const float yy = P[r * dout + c];
             if (a.has_bn) d = rstd * (d - m0 - XH[r * dout + c] * m1);
             if (a.has_relu) d = yy > 0.f ? d : 0.f;
-            dU[r * dout + c] = d;
+            if (valid) dU[r * dout + c] = d;
             dot += d * yy;
         }
         dot = sm_team_sum(dot);
-        for (int c = tl; c < dout; c += 16) {
-            const float d = dU[r * dout + c];
-            dU[r * dout + c] = project ? inv * (d - P[r * dout + c] * dot) : inv * d;
+        for (int c0 = 0; c0 < dout; c0 += 16) {
+            const int c = c0 + tl;
+            float v = 0.f;
+            if (c < dout && valid) {
+                const float d = dU[r * dout + c];
+                v = project ? inv * (d - P[r * dout + c] * dot) : inv * d;
+                dU[r * dout + c] = v;
+            }
+            // bias gradient = column sums of dU: the four rows of this wave first, then one LDS float atomic per
+            // wave and column (a serial column walk after the barrier held a whole wave back for ~4.5k cycles)
+            if (dbb) {
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if ((tid & 63) < 16 && c < dout) atomicAdd(&DB[c], v);
+            }
         }
     }
     __syncthreads();
-    // ---- db = column sums of dU ;  G = A^T dU (+ dU) ;  P = X W
+    SM_STAMP(1, 2);
     if (dbb)
-        for (int c = tid; c < dout; c += NT) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < n; ++r) s += dU[r * dout + c];
-            dbb[c] = s;
-        }
+        for (int c = tid; c < dout; c += NT) dbb[c] = DB[c];
+    SM_STAMP(1, 10);
     lds_mma<true, false>(A, n, dU, dout, n, dout, n, [&](int m, int c, float v) {
         G[m * dout + c] = a.add_self ? v + dU[m * dout + c] : v;
     });
+    SM_STAMP(1, 11);
     if (a.dadj)
-        lds_mma<false, false>(X, din, W, dout, n, dout, din, [&](int m, int c, float v) { P[m * dout + c] = v; });
+        lds_mma<false, false>(X, din, W, dout, n, dout, din, [&](int m, int c, float v) { P[m * dout + c] = v; },
+                              ((n + 15) / 16) * ((dout + 15) / 16));
+    SM_STAMP(1, 12);
     __syncthreads();
+    SM_STAMP(1, 3);
     // ---- dW = X^T G  -> this graph's slab
     lds_mma<true, false>(X, din, G, dout, din, dout, n, [&](int k, int c, float v) { dWb[k * dout + c] = v; });
+    SM_STAMP(1, 4);
     // ---- dXin = G W^T, accumulated into the gradient of the layer input
     if (a.dxin)
         lds_mma<false, true>(G, dout, W, dout, n, din, dout, [&](int r, int k, float v) {
@@ -312,11 +384,13 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
             DX[r * din + k] = tot;
             a.dxin[((long)b * n + r) * a.lddxin + k] = tot;
         });
+    SM_STAMP(1, 5);
     // ---- dA += dU P^T
     if (a.dadj)
         lds_mma<false, true>(dU, dout, P, dout, n, n, dout, [&](int r, int m, float v) {
             a.dadj[(long)b * n * n + r * n + m] = DA[r * n + m] + v;
         });
+    SM_STAMP(1, 6);
     // ---- BN-backward partials of layer l-1: (sum_k dX[r][k], sum_k dX[r][k] xhat[r][k]); xhat_{l-1} = X
     if (a.part2_prev) {
         __syncthreads();
@@ -335,6 +409,7 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
             }
         }
     }
+    SM_STAMP(1, 7);
 }
 
 size_t small_lds_floats_fwd(int B, int n, int din, int dout) {
@@ -342,7 +417,7 @@ size_t small_lds_floats_fwd(int B, int n, int din, int dout) {
            (size_t)B * n * 2 + 16;
 }
 size_t small_lds_floats_bwd(int B, int n, int din, int dout) {
-    return 2 * (size_t)n * n + 2 * (size_t)n * din + (size_t)din * dout + 4 * (size_t)n * dout + 4 * n +
+    return 2 * (size_t)n * n + 2 * (size_t)n * din + (size_t)din * dout + 4 * (size_t)n * dout + 4 * n + dout +
            (size_t)B * n * 2 + 16;
 }
 
@@ -372,7 +447,7 @@ void small_gcn_fwd(Seq& q, const float* adj, const float* x0, int ldx0, const fl
     if (!q.ok()) return;
     small_attr();
     SmallFwdArgs a{adj, x0, ldx0, yprev, ldyp, part_prev, stats_prev, xout, ldxo, W, bias, y, ldy, invn, part,
-                   B, n, din, dout, add_self, stats};
+                   B, n, din, dout, add_self, stats, sm_div(din)};
     hipLaunchKernelGGL(k_small_gcn_fwd, dim3(B), dim3(1024), small_lds_floats_fwd(B, n, din, dout) * sizeof(float),
                        q.stream, a);
     q.check_launch("small_gcn_fwd");
@@ -386,10 +461,16 @@ void small_gcn_bwd(Seq& q, const float* adj, const float* xin, int ldxin, const 
     if (!q.ok()) return;
     small_attr();
     SmallBwdArgs a{adj, xin, ldxin, W, y, ldy, xhat, ldxh, invn, stats, part2, dx, lddx, dxin, lddxin, part2_prev,
-                   dadj, dW, db, slab_stride, B, n, din, dout, add_self, has_bn, has_relu};
+                   dadj, dW, db, slab_stride, B, n, din, dout, add_self, has_bn, has_relu, sm_div(din), sm_div(dout)};
     hipLaunchKernelGGL(k_small_gcn_bwd, dim3(B), dim3(1024), small_lds_floats_bwd(B, n, din, dout) * sizeof(float),
                        q.stream, a);
     q.check_launch("small_gcn_bwd");
 }
+
+#ifdef DP_STAMP
+extern "C" __attribute__((visibility("default"))) int dp_debug_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
 
 }  // namespace dp
