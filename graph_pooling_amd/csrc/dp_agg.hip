@@ -28,6 +28,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define AGG_L2_EPS 1e-12f
 
+#ifdef DP_STAMP
+// diagnostic build only (see dp_small.hip): phase stamps of workgroup 0 of the last panel-kernel launch
+__device__ unsigned long long g_agg_stamps[16];
+#define AGG_STAMP(i)                                                                              \
+    do {                                                                                          \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_agg_stamps[i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define AGG_STAMP(i) \
+    do {             \
+    } while (0)
+#endif
+
 struct AggArgs {
     const float* A;      // [B, n, n]
     const float* V;      // [B, n, C] (ldv)
@@ -75,7 +88,7 @@ __device__ inline float agg_team_sum(float v) {
 
 // ---------------------------------------------------------------------------------------------------------
 // exact-fp32 accumulate: acc += op(A)[r0.., :] · V   (any adjacency values)
-template <bool TRANS, int CT, int AGG_RT>
+template <bool TRANS, int CT, int AGG_RT, int NW>
 __device__ __forceinline__ void accumulate_fp32(const AggArgs& a, int b, int r0, float* lds,
                                                 f32x4 (&acc)[AGG_RT / 16][CT]) {
     constexpr int MI = AGG_RT / 16;
@@ -132,13 +145,13 @@ __device__ __forceinline__ void accumulate_fp32(const AggArgs& a, int b, int r0,
                         acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][j], bf[j][cb], acc[rb][cb], 0, 0, 0);
         };
         load_b(wave, b0);
-        load_b(wave + 4, b1);
+        load_b(wave + NW, b1);
         // ---------------- panel -> LDS (everything in flight at once)
         if (a.dbg & 2) {
         } else if (!TRANS) {
             // rows r0..r0+RT-1, columns kbase..kbase+kw: pieces (row i, segment s) of 256 floats
             const int pieces = AGG_RT * segs;
-            for (int pc = wave; pc < pieces; pc += 4) {
+            for (int pc = wave; pc < pieces; pc += NW) {
                 const int i = pc / segs, s = pc % segs;
                 const int row = min(r0 + i, n - 1);
                 int col = kbase + s * 256 + lane * 4;
@@ -151,7 +164,7 @@ __device__ __forceinline__ void accumulate_fp32(const AggArgs& a, int b, int r0,
             constexpr int RPP = 256 / AGG_RT;            // panel rows per piece
             constexpr int LPR = AGG_RT / 4;              // lanes per row
             const int pieces = (((kw + 15) / 16) * 16) / RPP;
-            for (int pc = wave; pc < pieces; pc += 4) {
+            for (int pc = wave; pc < pieces; pc += NW) {
                 const int k = min(kbase + pc * RPP + lane / LPR, n - 1);
                 const int col = min(r0 + (lane % LPR) * 4, n - 4);
                 dma16(A + (long)k * n + col, lds + pc * 256);
@@ -161,23 +174,23 @@ __device__ __forceinline__ void accumulate_fp32(const AggArgs& a, int b, int r0,
         if (kw & 15) {
             // zero the padded K tail [kw, ceil16(kw)) of the panel (it holds finite duplicates)
             const int k1 = steps * 16, tail = k1 - kw;
-            for (int e = threadIdx.x; e < tail * AGG_RT; e += 256) {
+            for (int e = threadIdx.x; e < tail * AGG_RT; e += NW * 64) {
                 if (!TRANS) lds[(e / tail) * ldp + kw + e % tail] = 0.f;
                 else lds[(kw + e / AGG_RT) * AGG_RT + e % AGG_RT] = 0.f;
             }
             __syncthreads();
         }
         const int send = (a.dbg & 1) ? 0 : steps;
-        for (int step = wave; step < send; step += 12) {
-            load_b(step + 8, b2);
+        for (int step = wave; step < send; step += 3 * NW) {
+            load_b(step + 2 * NW, b2);
             mma(step, b0);
-            if (step + 4 < send) {
-                load_b(step + 12, b0);
-                mma(step + 4, b1);
+            if (step + NW < send) {
+                load_b(step + 3 * NW, b0);
+                mma(step + NW, b1);
             }
-            if (step + 8 < send) {
-                load_b(step + 16, b1);
-                mma(step + 8, b2);
+            if (step + 2 * NW < send) {
+                load_b(step + 4 * NW, b1);
+                mma(step + 2 * NW, b2);
             }
         }
         __syncthreads();                               // panel may be overwritten (next K panel / reduction)
@@ -199,8 +212,8 @@ __device__ inline void dma16_raw(const void* src, void* lds_dst) {
 // result is the same fp32-accumulated sum of exact products the fp32 MFMA gives — at 16/3 of its rate and half
 // the adjacency bytes.  The packed operand is already oriented (A or A^T), so there is one loop for both passes.
 // LDS panel image: [RT][ldp] bf16, ldp = 8 (mod 128)  -> ds_read_b128 A-fragment reads are conflict-free.
-template <int CT, int AGG_RT>
-__device__ __forceinline__ void accumulate_bf16(const AggArgs& a, int b, int r0, float* ldsf,
+template <int CT, int AGG_RT, int NW>
+__device__ __forceinline__ bool accumulate_bf16(const AggArgs& a, int b, int r0, float* ldsf, int flag,
                                                 f32x4 (&acc)[AGG_RT / 16][CT]) {
     constexpr int MI = AGG_RT / 16;
     unsigned short* lds = reinterpret_cast<unsigned short*>(ldsf);
@@ -241,32 +254,48 @@ __device__ __forceinline__ void accumulate_bf16(const AggArgs& a, int b, int r0,
                                                                           __builtin_bit_cast(agg_bf16x8, bf[p][cb]),
                                                                           acc[rb][cb], 0, 0, 0);
     };
-    load_b(wave, f0);
-    load_b(wave + 4, f1);
-    // rows r0..r0+RT-1 of the packed operand: pieces (row i, segment s) of 512 bf16 = 1 KiB
+    AGG_STAMP(1);
     {
-        const int pieces = AGG_RT * segs;
-        for (int pc = wave; pc < pieces; pc += 4) {
-            const int i = pc / segs, s = pc % segs;
-            const int row = min(r0 + i, n - 1);
-            const int col = min(s * 512 + lane * 8, np - 8);   // clamp: finite duplicates, they meet zero V planes
-            dma16_raw(A + (long)row * np + col, lds + i * ldp + s * 512);
+        load_b(wave, f0);
+        load_b(wave + NW, f1);
+        // rows r0..r0+RT-1 of the packed operand: pieces (row i, segment s) of 512 bf16 = 1 KiB
+#pragma unroll
+        for (int i = wave; i < AGG_RT; i += NW) {
+            const unsigned short* arow = A + (long)min(r0 + i, n - 1) * np;
+            for (int s = 0; s < segs; ++s) {
+                const int col = min(s * 512 + lane * 8, np - 8);   // clamp: finite duplicates, they meet zero V planes
+                dma16_raw(arow + col, lds + i * ldp + s * 512);
+            }
+        }
+        AGG_STAMP(2);
+        // The exactness flag was requested before any of the loads above; only now is it looked at, so its
+        // latency hides behind their issue.  A non-exact adjacency (rare) drains the speculative DMA and
+        // hands the tile to the fp32 path.
+        if (__builtin_amdgcn_readfirstlane(flag) != 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            return false;
         }
         __syncthreads();
+        AGG_STAMP(3);
     }
-    for (int step = wave; step < steps; step += 8) {
+    for (int step = wave; step < steps; step += 2 * NW) {
         mma(step, f0);
-        if (step + 4 < steps) {
-            load_b(step + 8, f0);
-            mma(step + 4, f1);
-            load_b(step + 12, f1);
+        if (step + NW < steps) {
+            load_b(step + 2 * NW, f0);
+            mma(step + NW, f1);
+            load_b(step + 3 * NW, f1);
         }
     }
+    AGG_STAMP(4);
     __syncthreads();
+    AGG_STAMP(5);
+    return true;
 }
 
-template <bool TRANS, int CT, int AGG_RT>
-__global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
+template <bool TRANS, int CT, int AGG_RT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_aggregate(AggArgs a) {
+    constexpr int NT = NW * 64;
     constexpr int MI = AGG_RT / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // XCD-aware work mapping: consecutive block ids are dealt round-robin over the 8 XCDs (each with its own
@@ -274,6 +303,7 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     // (graph, row tile) items: the 16 row tiles of a graph then share one L2 for their V operand instead of
     // fetching it into all eight (measured: 32 MB -> ~22 MB of fabric reads per DD launch).
     if (a.run_if && __builtin_amdgcn_readfirstlane(*a.run_if) == 0) return;
+    AGG_STAMP(0);
     const int nwg = gridDim.x, tiles = a.tiles;
     int wid;
     {
@@ -288,20 +318,19 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
 
-    const bool use_bf16 = a.pk_A != nullptr && __builtin_amdgcn_readfirstlane(*a.pk_flag) == 0;
+    const bool packed = a.pk_A != nullptr;
+    const int flag = packed ? *a.pk_flag : 1;          // consumed inside accumulate_bf16, after its loads
     constexpr int CTP = CT * 16 + 1;
     float* red = lds;                                  // [wave][RT][CTP]; overlays the panel
-    float* tile = red + 4 * AGG_RT * CTP;              // summed tile [RT][CTP]
+    float* tile = red + NW * AGG_RT * CTP;              // summed tile [RT][CTP]
     {
         f32x4 acc[MI][CT];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < CT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (use_bf16)
-            accumulate_bf16<CT, AGG_RT>(a, b, r0, lds, acc);
-        else
-            accumulate_fp32<TRANS, CT, AGG_RT>(a, b, r0, lds, acc);
+        if (!(packed && accumulate_bf16<CT, AGG_RT, NW>(a, b, r0, lds, flag, acc)))
+            accumulate_fp32<TRANS, CT, AGG_RT, NW>(a, b, r0, lds, acc);
 
         // ---------------- cross-wave reduction through LDS
 #pragma unroll
@@ -312,37 +341,68 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
                 for (int r = 0; r < 4; ++r)
                     red[(wave * AGG_RT + rb * 16 + kq * 4 + r) * CTP + cb * 16 + l15] = acc[rb][cb][r];
         __syncthreads();
-        for (int e = threadIdx.x; e < AGG_RT * CT * 16; e += 256) {
+        AGG_STAMP(6);
+        constexpr int TOT = AGG_RT * CT * 16;
+        constexpr int NE = (TOT + NT - 1) / NT;         // elements per thread
+        float sum[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {                  // all LDS reads of the NW-way sum in flight together
+            const int e = min((int)threadIdx.x + k * NT, TOT - 1);
             const int r = e / (CT * 16), c = e % (CT * 16);
-            const int cg = c;
-            const float s = red[(0 * AGG_RT + r) * CTP + c] + red[(1 * AGG_RT + r) * CTP + c] +
-                            red[(2 * AGG_RT + r) * CTP + c] + red[(3 * AGG_RT + r) * CTP + c];
-            if (a.U) {
+            float t = red[r * CTP + c];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) t += red[(w * AGG_RT + r) * CTP + c];
+            sum[k] = t;
+        }
+        if (a.U) {
+            const bool accum = a.beta != 0.f;
+            float old[NE];
+            if (accum) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {          // clamped addresses: one unpredicated batch
+                    const int e = min((int)threadIdx.x + k * NT, TOT - 1);
+                    const int r = e / (CT * 16), c = e % (CT * 16);
+                    old[k] = a.U[((long)b * n + min(r0 + r, n - 1)) * a.ldu + min(c, a.C - 1)];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int e = threadIdx.x + k * NT;
+                const int r = e / (CT * 16), c = e % (CT * 16);
                 const int row = r0 + r;
-                if (row < n && cg < a.C) {
-                    float* u = a.U + ((long)b * n + row) * a.ldu + cg;
-                    *u = (a.beta != 0.f) ? s + a.beta * (*u) : s;
-                }
-            } else {
-                // fold bias (+ the add_self operand) in here, with ONE round of coalesced global loads, so the
-                // row passes below read LDS only
-                float u = s;
-                if (c < a.C) {
-                    const int g = (a.g.G == 2 && c >= a.g.c0[1]) ? 1 : 0;
-                    const float* bias = a.bias.p[g];
-                    if (bias) u += bias[c - a.g.c0[g]];
-                    if (a.P && r0 + r < n) u += a.P[((long)b * n + r0 + r) * a.ldv + c];
-                }
-                tile[r * CTP + c] = u;
+                if (e < TOT && row < n && c < a.C)
+                    a.U[((long)b * n + row) * a.ldu + c] = accum ? sum[k] + a.beta * old[k] : sum[k];
+            }
+        } else {
+            // fold bias (+ the add_self operand) in here, with ONE round of coalesced global loads, so the
+            // row passes below read LDS only
+            float add[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int e = min((int)threadIdx.x + k * NT, TOT - 1);
+                const int r = e / (CT * 16), c = e % (CT * 16);
+                const int cc = min(c, a.C - 1);
+                const int g = (a.g.G == 2 && cc >= a.g.c0[1]) ? 1 : 0;
+                const float* bias = a.bias.p[g];
+                float u = bias ? bias[cc - a.g.c0[g]] : 0.f;
+                if (a.P) u += a.P[((long)b * n + min(r0 + r, n - 1)) * a.ldv + cc];
+                add[k] = u;
+            }
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int e = threadIdx.x + k * NT;
+                const int r = e / (CT * 16), c = e % (CT * 16);
+                if (e < TOT) tile[r * CTP + c] = c < a.C ? sum[k] + add[k] : sum[k];
             }
         }
     }
+    AGG_STAMP(7);
     if (a.U) return;
     __syncthreads();
 
     // ---------------- fused GraphConv tail (encoders.py:966-972): one 16-lane team per (row, group)
     const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
-    for (int it = team; it < AGG_RT * a.g.G; it += 16) {
+    for (int it = team; it < AGG_RT * a.g.G; it += NT / 16) {
         const int r = it / a.g.G, g = it % a.g.G;
         const int node = r0 + r;
         if (node >= n) continue;
@@ -378,6 +438,7 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a) {
             }
         }
     }
+    AGG_STAMP(8);
 }
 
 
@@ -817,9 +878,9 @@ static size_t agg_panel_floats(bool trans, int n, int RT) {
     const size_t pk = ((size_t)RT * (((n + 511) / 512) * 512 + 8) * 2 + 3) / 4;     // bf16 panel, in floats
     return ((panel > pk ? panel : pk) + 3) & ~size_t(3);
 }
-static size_t agg_lds_bytes(bool trans, int n, int CT, int RT) {
+static size_t agg_lds_bytes(bool trans, int n, int CT, int RT, int NW = 4) {
     const size_t panel = agg_panel_floats(trans, n, RT);
-    const size_t red = (size_t)5 * RT * (CT * 16 + 1);
+    const size_t red = (size_t)(NW + 1) * RT * (CT * 16 + 1);
     return (panel > red ? panel : red) * sizeof(float);    // the reduction area overlays the panel
 }
 // 16-row tiles when 32-row tiles would leave CUs idle (< 1 workgroup per CU): twice the workgroups.  Otherwise 32
@@ -841,12 +902,12 @@ bool aggregate_supported(const float* A, int n, int C, bool trans) {
     return agg_lds_bytes(trans, n, agg_ct(C), 16) <= 160 * 1024;
 }
 
-template <bool TRANS, int CT, int RT>
+template <bool TRANS, int CT, int RT, int NW>
 static void launch_agg_rt(Seq& q, const AggArgs& a, int B) {
-    const size_t lds = agg_lds_bytes(TRANS, a.n, CT, RT);
+    const size_t lds = agg_lds_bytes(TRANS, a.n, CT, RT, NW);
     static bool attr_done = false;   // per instantiation: allow > 64 KiB of dynamic LDS
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate<TRANS, CT, RT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate<TRANS, CT, RT, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
@@ -855,12 +916,16 @@ static void launch_agg_rt(Seq& q, const AggArgs& a, int B) {
     aa.vs_ct = (a.C + 15) / 16;
     static const int dbg = getenv("DP_AGG_DEBUG") ? atoi(getenv("DP_AGG_DEBUG")) : 0;
     aa.dbg = dbg;
-    hipLaunchKernelGGL((k_aggregate<TRANS, CT, RT>), dim3(aa.tiles * B), dim3(256), lds, q.stream, aa);
+    hipLaunchKernelGGL((k_aggregate<TRANS, CT, RT, NW>), dim3(aa.tiles * B), dim3(NW * 64), lds, q.stream, aa);
 }
 template <bool TRANS, int CT>
 static void launch_agg(Seq& q, const AggArgs& a, int B) {
-    if (agg_row_tile(B, a.n, a.C, TRANS) == 32) launch_agg_rt<TRANS, CT, 32>(q, a, B);
-    else launch_agg_rt<TRANS, CT, 16>(q, a, B);     // (64-row tiles: measured slower at DD, 0.437 vs 0.417 ms)
+    // (8 waves per 32-row tile, NW = 8: measured slower at DD, 9.5 vs 8.0 us per launch and 0.427 vs 0.407 ms per
+    // step -- the launch is bound by the L2 burst of V fragments, not by per-wave latency, and the extra waves only
+    // add barrier and reduction work.  64-row tiles: also slower, 0.437 vs 0.417 ms.)
+    if (agg_row_tile(B, a.n, a.C, TRANS) == 32) {
+        launch_agg_rt<TRANS, CT, 32, 4>(q, a, B);
+    } else launch_agg_rt<TRANS, CT, 16, 4>(q, a, B);     // (64-row tiles: measured slower at DD, 0.437 vs 0.417 ms)
 }
 
 template <bool TRANS>
@@ -1053,5 +1118,11 @@ bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, cons
     q.check_launch("aggregate_rownorm_fwd");
     return true;
 }
+
+#ifdef DP_STAMP
+extern "C" __attribute__((visibility("default"))) int dp_debug_agg_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_agg_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
 
 }  // namespace dp
