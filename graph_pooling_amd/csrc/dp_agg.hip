@@ -30,10 +30,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef DP_STAMP
 // diagnostic build only (see dp_small.hip): phase stamps of workgroup 0 of the last panel-kernel launch
-__device__ unsigned long long g_agg_stamps[16];
+__device__ unsigned long long g_agg_stamps[32];   // [0,16) plain-store launches, [16,32) fused-tail launches
 #define AGG_STAMP(i)                                                                              \
     do {                                                                                          \
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_agg_stamps[i] = __builtin_amdgcn_s_memtime(); \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_agg_stamps[(i) + (a.U ? 0 : 16)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define AGG_STAMP(i) \
@@ -78,13 +78,7 @@ __device__ inline void dma16(const float* src, float* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-__device__ inline float agg_team_sum(float v) {
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
-    return v;
-}
+__device__ __forceinline__ float agg_team_sum(float v) { return row16_sum(v); }
 
 // ---------------------------------------------------------------------------------------------------------
 // exact-fp32 accumulate: acc += op(A)[r0.., :] · V   (any adjacency values)
@@ -255,6 +249,8 @@ __device__ __forceinline__ bool accumulate_bf16(const AggArgs& a, int b, int r0,
                                                                           acc[rb][cb], 0, 0, 0);
     };
     AGG_STAMP(1);
+    // (Asking for four k-steps of V up front instead of two, registers permitting: slower, 11.9 vs 8.0 us per DD
+    // launch -- a deeper burst only queues the adjacency panel behind more V traffic.)
     {
         load_b(wave, f0);
         load_b(wave + NW, f1);
@@ -321,6 +317,31 @@ __global__ __launch_bounds__(NW * 64) void k_aggregate(AggArgs a) {
     const bool packed = a.pk_A != nullptr;
     const int flag = packed ? *a.pk_flag : 1;          // consumed inside accumulate_bf16, after its loads
     constexpr int CTP = CT * 16 + 1;
+    constexpr int TOT = AGG_RT * CT * 16;
+    constexpr int NE = (TOT + NT - 1) / NT;            // output elements per thread
+    // Epilogue operands do not depend on the product: ask for them before anything else so their latency is
+    // spent under the multiply (plain store: the old U when beta != 0; fused tail: bias + the add_self operand).
+    float pre[NE], preb[NE];                           // kept apart: adding them here would wait for each load
+    {
+        const bool accum = a.U && a.beta != 0.f;
+        const float* src = a.U ? a.U : a.P;
+        const int ld = a.U ? a.ldu : a.ldv;
+        const bool want = a.U ? accum : a.P != nullptr;
+        const int c01 = (!a.U && a.g.G == 2) ? a.g.c0[1] : 0x7fffffff;
+        const float* bias0 = a.U ? nullptr : a.bias.p[0];
+        const float* bias1 = a.U ? nullptr : a.bias.p[1];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = min((int)threadIdx.x + k * NT, TOT - 1);
+            const int r = e / (CT * 16), cc = min(e % (CT * 16), a.C - 1);
+            pre[k] = 0.f;
+            preb[k] = 0.f;
+            if (want) pre[k] = src[((long)b * n + min(r0 + r, n - 1)) * ld + cc];
+            const float* bias = cc >= c01 ? bias1 : bias0;
+            const int cb = cc >= c01 ? cc - c01 : cc - (a.U ? 0 : a.g.c0[0]);
+            if (bias) preb[k] = bias[cb];
+        }
+    }
     float* red = lds;                                  // [wave][RT][CTP]; overlays the panel
     float* tile = red + NW * AGG_RT * CTP;              // summed tile [RT][CTP]
     {
@@ -342,8 +363,6 @@ __global__ __launch_bounds__(NW * 64) void k_aggregate(AggArgs a) {
                     red[(wave * AGG_RT + rb * 16 + kq * 4 + r) * CTP + cb * 16 + l15] = acc[rb][cb][r];
         __syncthreads();
         AGG_STAMP(6);
-        constexpr int TOT = AGG_RT * CT * 16;
-        constexpr int NE = (TOT + NT - 1) / NT;         // elements per thread
         float sum[NE];
 #pragma unroll
         for (int k = 0; k < NE; ++k) {                  // all LDS reads of the NW-way sum in flight together
@@ -354,45 +373,16 @@ __global__ __launch_bounds__(NW * 64) void k_aggregate(AggArgs a) {
             for (int w = 1; w < NW; ++w) t += red[(w * AGG_RT + r) * CTP + c];
             sum[k] = t;
         }
-        if (a.U) {
-            const bool accum = a.beta != 0.f;
-            float old[NE];
-            if (accum) {
 #pragma unroll
-                for (int k = 0; k < NE; ++k) {          // clamped addresses: one unpredicated batch
-                    const int e = min((int)threadIdx.x + k * NT, TOT - 1);
-                    const int r = e / (CT * 16), c = e % (CT * 16);
-                    old[k] = a.U[((long)b * n + min(r0 + r, n - 1)) * a.ldu + min(c, a.C - 1)];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const int e = threadIdx.x + k * NT;
-                const int r = e / (CT * 16), c = e % (CT * 16);
+        for (int k = 0; k < NE; ++k) {
+            const int e = threadIdx.x + k * NT;
+            const int r = e / (CT * 16), c = e % (CT * 16);
+            if (a.U) {
                 const int row = r0 + r;
                 if (e < TOT && row < n && c < a.C)
-                    a.U[((long)b * n + row) * a.ldu + c] = accum ? sum[k] + a.beta * old[k] : sum[k];
-            }
-        } else {
-            // fold bias (+ the add_self operand) in here, with ONE round of coalesced global loads, so the
-            // row passes below read LDS only
-            float add[NE];
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const int e = min((int)threadIdx.x + k * NT, TOT - 1);
-                const int r = e / (CT * 16), c = e % (CT * 16);
-                const int cc = min(c, a.C - 1);
-                const int g = (a.g.G == 2 && cc >= a.g.c0[1]) ? 1 : 0;
-                const float* bias = a.bias.p[g];
-                float u = bias ? bias[cc - a.g.c0[g]] : 0.f;
-                if (a.P) u += a.P[((long)b * n + min(r0 + r, n - 1)) * a.ldv + cc];
-                add[k] = u;
-            }
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const int e = threadIdx.x + k * NT;
-                const int r = e / (CT * 16), c = e % (CT * 16);
-                if (e < TOT) tile[r * CTP + c] = c < a.C ? sum[k] + add[k] : sum[k];
+                    a.U[((long)b * n + row) * a.ldu + c] = a.beta != 0.f ? sum[k] + a.beta * pre[k] : sum[k];
+            } else if (e < TOT) {
+                tile[r * CTP + c] = c < a.C ? (sum[k] + preb[k]) + pre[k] : sum[k];
             }
         }
     }
@@ -401,40 +391,58 @@ __global__ __launch_bounds__(NW * 64) void k_aggregate(AggArgs a) {
     __syncthreads();
 
     // ---------------- fused GraphConv tail (encoders.py:966-972): one 16-lane team per (row, group)
+    // All of a team's (row, group) items are in flight together (unrolled, predicated instead of branched) and a
+    // row's values stay in registers across the three passes: the tail is a chain of LDS reads and 16-lane sums,
+    // and run one item after another it costs as much as the multiply.
     const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
-    for (int it = team; it < AGG_RT * a.g.G; it += NT / 16) {
-        const int r = it / a.g.G, g = it % a.g.G;
+    constexpr int TEAMS = NT / 16;
+    constexpr int ITER = (AGG_RT * 2 + TEAMS - 1) / TEAMS;
+    const int G = a.g.G;
+#pragma unroll
+    for (int j = 0; j < ITER; ++j) {
+        if (j * TEAMS >= AGG_RT * G) break;             // uniform
+        const int it = team + j * TEAMS;
+        const int r = min(G == 2 ? it >> 1 : it, AGG_RT - 1), g = G == 2 ? (it & 1) : 0;
         const int node = r0 + r;
-        if (node >= n) continue;
-        const long row = (long)b * n + node;
-        const int c0 = a.g.c0[g], w = a.g.w[g];
+        const bool on = it < AGG_RT * G && node < n;
+        const long row = (long)b * n + min(node, n - 1);
+        const int c0 = g ? a.g.c0[1] : a.g.c0[0], w = g ? a.g.w[1] : a.g.w[0];
         const float* u = tile + r * CTP + c0;
+        float uv[CT];
         float ss = 0.f;
-        for (int c = tl; c < w; c += 16) ss += u[c] * u[c];
+#pragma unroll
+        for (int k = 0; k < CT; ++k) {
+            const int c = tl + 16 * k;
+            const float t = u[min(c, w - 1)];
+            uv[k] = c < w ? t : 0.f;
+            ss += uv[k] * uv[k];
+        }
         ss = agg_team_sum(ss);
         const float inv = a.normalize ? 1.f / fmaxf(sqrtf(ss), AGG_L2_EPS) : 1.f;
-        float* y = a.yout.p[g] + row * a.yout.ld[g];
+        float* y = (g ? a.yout.p[1] : a.yout.p[0]) + row * (g ? a.yout.ld[1] : a.yout.ld[0]);
         float s1 = 0.f;
-        for (int c = tl; c < w; c += 16) {
-            const float v = u[c] * inv;
-            y[c] = v;
-            s1 += a.stats_mode == 1 ? fmaxf(v, 0.f) : v;
+#pragma unroll
+        for (int k = 0; k < CT; ++k) {
+            const int c = tl + 16 * k;
+            uv[k] *= inv;
+            if (on && c < w) y[c] = uv[k];
+            if (a.stats_mode == 1) uv[k] = fmaxf(uv[k], 0.f);
+            s1 += uv[k];
         }
-        if (tl == 0 && a.invn) a.invn[row * a.g.G + g] = inv;
+        if (on && tl == 0 && a.invn) a.invn[row * G + g] = inv;
         if (a.stats_mode && a.part) {
             s1 = agg_team_sum(s1);
             const float mean = s1 / (float)w;
             float m2 = 0.f;
-            for (int c = tl; c < w; c += 16) {
-                float v = u[c] * inv;
-                if (a.stats_mode == 1) v = fmaxf(v, 0.f);
-                v -= mean;
+#pragma unroll
+            for (int k = 0; k < CT; ++k) {
+                const float v = (tl + 16 * k < w) ? uv[k] - mean : 0.f;
                 m2 += v * v;
             }
             m2 = agg_team_sum(m2);
-            if (tl == 0) {
-                a.part[(row * a.g.G + g) * 2 + 0] = mean;
-                a.part[(row * a.g.G + g) * 2 + 1] = m2;
+            if (on && tl == 0) {
+                a.part[(row * G + g) * 2 + 0] = mean;
+                a.part[(row * G + g) * 2 + 1] = m2;
             }
         }
     }
@@ -922,7 +930,7 @@ template <bool TRANS, int CT>
 static void launch_agg(Seq& q, const AggArgs& a, int B) {
     // (8 waves per 32-row tile, NW = 8: measured slower at DD, 9.5 vs 8.0 us per launch and 0.427 vs 0.407 ms per
     // step -- the launch is bound by the L2 burst of V fragments, not by per-wave latency, and the extra waves only
-    // add barrier and reduction work.  64-row tiles: also slower, 0.437 vs 0.417 ms.)
+    // add barrier and reduction work.  64-row tiles: also slower, 9.1 us per launch, 0.412 vs 0.398 ms.)
     if (agg_row_tile(B, a.n, a.C, TRANS) == 32) {
         launch_agg_rt<TRANS, CT, 32, 4>(q, a, B);
     } else launch_agg_rt<TRANS, CT, 16, 4>(q, a, B);     // (64-row tiles: measured slower at DD, 0.437 vs 0.417 ms)
@@ -1121,7 +1129,7 @@ bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, cons
 
 #ifdef DP_STAMP
 extern "C" __attribute__((visibility("default"))) int dp_debug_agg_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_agg_stamps), sizeof(unsigned long long) * 16);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_agg_stamps), sizeof(unsigned long long) * 32);
 }
 #endif
 

@@ -22,6 +22,44 @@ const char* last_error();
         }                                            \
     } while (0)
 
+// ----------------------------------------------------------------- cross-lane reductions on DPP
+// __shfl_xor compiles to ds_bpermute_b32 (an LDS-pipe round trip per step); these run in the VALU.  A DPP row is 16
+// lanes: two quad permutes, then the half-row and the row mirror, leave the row's total in every lane.  The wave
+// forms add row_bcast15 / row_bcast31 (lane 63 ends up with the total of all four rows) and a readlane, so every
+// lane receives the same bits.
+#ifdef __HIPCC__
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_src(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, BOUND));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_src<0xB1, 0xF, true>(0.f, v);       // quad_perm [1,0,3,2]
+    v += dpp_src<0x4E, 0xF, true>(0.f, v);       // quad_perm [2,3,0,1]
+    v += dpp_src<0x141, 0xF, true>(0.f, v);      // row_half_mirror
+    v += dpp_src<0x140, 0xF, true>(0.f, v);      // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_src<0xB1, 0xF, true>(v, v));
+    v = fmaxf(v, dpp_src<0x4E, 0xF, true>(v, v));
+    v = fmaxf(v, dpp_src<0x141, 0xF, true>(v, v));
+    v = fmaxf(v, dpp_src<0x140, 0xF, true>(v, v));
+    return v;
+}
+__device__ __forceinline__ float wave64_sum(float v) {
+    v = row16_sum(v);
+    v += dpp_src<0x142, 0xA, false>(0.f, v);     // row_bcast15 into rows 1 and 3
+    v += dpp_src<0x143, 0xC, false>(0.f, v);     // row_bcast31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave64_max(float v) {
+    v = row16_max(v);
+    v = fmaxf(v, dpp_src<0x142, 0xA, false>(v, v));
+    v = fmaxf(v, dpp_src<0x143, 0xC, false>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#endif
+
 // A launch sequence records the first HIP error it meets; later launches are skipped.
 struct Seq {
     hipStream_t stream;

@@ -12,8 +12,7 @@ constexpr int HEAD_FWD_LDS_FLOATS = 30 * 1024;    // weights + biases + two acti
 constexpr int HEAD_BWD_LDS_FLOATS = 38 * 1024;    // weights + saved activations of the batch + two gradient blocks
 
 __device__ inline float head_wave_sum(float v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return wave64_sum(v);
 }
 
 // dst[i] = src[i] for i < cnt, 16 loads per thread in flight (clamped addresses, no branch around the loads)

@@ -18,7 +18,7 @@ namespace dp {
 typedef float lk_f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ inline float lk_block_sum(float v, float* red) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = wave64_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void k_sqnorm_partials(const float* g, long n,
     __shared__ float red[4];
     float s = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s = wave64_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* p, float* g, float* m,
         float s = 0.f;
         if (partial)
             for (int i = threadIdx.x; i < npartial; i += 64) s += partial[i];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        s = wave64_sum(s);
         if (threadIdx.x == 0) {
             const float tn = sqrtf(s);
             float c = 1.f;

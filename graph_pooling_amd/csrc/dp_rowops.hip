@@ -9,18 +9,10 @@ namespace dp {
 #define BN_EPS 1e-5f
 
 __device__ inline float team_sum(float v) {
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
-    return v;
+    return row16_sum(v);
 }
 __device__ inline float team_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 8, 16));
-    v = fmaxf(v, __shfl_xor(v, 4, 16));
-    v = fmaxf(v, __shfl_xor(v, 2, 16));
-    v = fmaxf(v, __shfl_xor(v, 1, 16));
-    return v;
+    return row16_max(v);
 }
 
 static inline int team_grid(long items) {

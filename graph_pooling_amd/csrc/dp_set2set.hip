@@ -41,23 +41,19 @@ S2SLayout s2s_layout(int B, int n, int d) {
 __device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 __device__ inline float team16_sum(float v) {
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
-    return v;
+    return row16_sum(v);
 }
 
 // block-wide reductions over 256 threads (red: 8 floats of LDS)
 __device__ inline float block_max(float v, float* red) {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = wave64_max(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 __device__ inline float block_sum(float v, float* red) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = wave64_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();

@@ -31,11 +31,7 @@ __device__ unsigned long long g_small_stamps[2][32];
 namespace {
 
 __device__ inline float sm_team_sum(float v) {
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
-    return v;
+    return row16_sum(v);
 }
 
 typedef float sm_f32x4 __attribute__((ext_vector_type(4)));
