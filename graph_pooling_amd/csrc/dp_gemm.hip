@@ -64,77 +64,95 @@ struct Slab {
     f32x4 v[SLOTS];
 };
 
-// `KCONTIG`: element (r,k) at p[r*ld + k], else at p[k*ld + r].
+// `KCONTIG`: element (r,k) at p[r*ld + k], else at p[k*ld + r].  A slot is four elements along the operand's
+// contiguous dimension c (extent cmax); o is the other dimension (extent omax).
+//
+// slab_load only ISSUES loads: one 16-byte load per slot from a clamped, always-valid address, no predicate and no
+// branch around it (a branch around a load makes hipcc wait for that load before the join; the version with
+// per-element predicated loads for rows that are not 16-byte aligned -- F = 89, K = 50, 90 in the DD model -- had 168
+// `s_waitcnt vmcnt(0)` in one kernel).  The rows need not be 16-byte aligned: global dwordx4 loads only need dword
+// alignment on gfx9 under HSA.  A slot that sticks out past cmax is read shifted back so that it ENDS at cmax;
+// slab_store undoes the shift and zeroes what lies outside, after the wait the LDS write needs anyway.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
 template <int R, bool KCONTIG>
-__device__ inline void slab_load(const float* __restrict__ p, int ld, int r0, int k0, int rmax, int kmax, bool vec,
-                                 Slab<R>& s) {
+__device__ __forceinline__ void slab_coords(int slot, int r0, int k0, int& c, int& o) {
+    int r, k;
+    if (KCONTIG) {
+        r = slot / (KT / 4);
+        k = (slot % (KT / 4)) * 4;
+    } else {
+        k = slot / (R / 4);
+        r = (slot % (R / 4)) * 4;
+    }
+    c = KCONTIG ? k0 + k : r0 + r;
+    o = KCONTIG ? r0 + r : k0 + k;
+}
+
+// QUAD = false serves operands with an extent below 4 in the contiguous dimension (no 16-byte load fits).
+template <int R, bool KCONTIG, bool QUAD>
+__device__ inline void slab_load(const float* __restrict__ p, int ld, int r0, int k0, int rmax, int kmax, Slab<R>& s) {
     const int t = threadIdx.x;
+    const int cmax = KCONTIG ? kmax : rmax, omax = KCONTIG ? rmax : kmax;
 #pragma unroll
     for (int i = 0; i < Slab<R>::SLOTS; ++i) {
-        const int slot = t + i * 256;
-        f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (slot < R * KT / 4) {
-            int r, k;   // first element of the slot; the 4 elements run along the contiguous dimension
-            if (KCONTIG) {
-                r = slot / (KT / 4);
-                k = (slot % (KT / 4)) * 4;
-            } else {
-                k = slot / (R / 4);
-                r = (slot % (R / 4)) * 4;
-            }
-            const int gr = r0 + r, gk = k0 + k;
-            if (KCONTIG) {
-                if (gr < rmax) {
-                    const float* q = p + (long)gr * ld + gk;
-                    if (vec && gk + 3 < kmax) {
-                        val = *reinterpret_cast<const f32x4*>(q);
-                    } else {
+        const int slot = min(t + i * 256, R * KT / 4 - 1);
+        int c, o;
+        slab_coords<R, KCONTIG>(slot, r0, k0, c, o);
+        const float* q = p + (long)min(o, omax - 1) * ld;
+        if (QUAD) {
+            s.v[i] = *reinterpret_cast<const f32x4_u*>(q + min(c, cmax - 4));
+        } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (gk + j < kmax) val[j] = q[j];
-                    }
-                }
-            } else {
-                if (gk < kmax) {
-                    const float* q = p + (long)gk * ld + gr;
-                    if (vec && gr + 3 < rmax) {
-                        val = *reinterpret_cast<const f32x4*>(q);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (gr + j < rmax) val[j] = q[j];
-                    }
-                }
-            }
+            for (int j = 0; j < 4; ++j) s.v[i][j] = q[min(c + j, cmax - 1)];
         }
-        s.v[i] = val;
     }
 }
 
-template <int R, bool KCONTIG>
-__device__ inline void slab_store(float* lds, const Slab<R>& s) {
+template <int R, bool KCONTIG, bool QUAD>
+__device__ inline void slab_store(float* lds, const Slab<R>& s, int r0, int k0, int rmax, int kmax) {
     using L = LdsImage<R, KCONTIG>;
     const int t = threadIdx.x;
+    const int cmax = KCONTIG ? kmax : rmax, omax = KCONTIG ? rmax : kmax;
 #pragma unroll
     for (int i = 0; i < Slab<R>::SLOTS; ++i) {
         const int slot = t + i * 256;
         if (slot < R * KT / 4) {
+            int c, o;
+            slab_coords<R, KCONTIG>(slot, r0, k0, c, o);
+            f32x4 v = s.v[i];
+            const bool ov = o < omax;
+            if (QUAD) {
+                // the load was shifted back by sh elements (0 for a whole slot, >= 4: all of it lies outside); no
+                // branch on the shape here, so the wait for the slab stays a counted one
+                const int sh = c - min(c, cmax - 4);
+                f32x4 w;
+                w[0] = sh == 0 ? v[0] : sh == 1 ? v[1] : sh == 2 ? v[2] : sh == 3 ? v[3] : 0.f;
+                w[1] = sh == 0 ? v[1] : sh == 1 ? v[2] : sh == 2 ? v[3] : 0.f;
+                w[2] = sh == 0 ? v[2] : sh == 1 ? v[3] : 0.f;
+                w[3] = sh == 0 ? v[3] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ov ? w[j] : 0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (ov && c + j < cmax) ? v[j] : 0.f;
+            }
             if (KCONTIG) {
                 const int r = slot / (KT / 4), k = (slot % (KT / 4)) * 4;
                 float* d = lds + L::addr(r, k);   // 8-byte aligned (row stride 34 floats)
-                d[0] = s.v[i][0];
-                d[1] = s.v[i][1];
-                d[2] = s.v[i][2];
-                d[3] = s.v[i][3];
+                d[0] = v[0];
+                d[1] = v[1];
+                d[2] = v[2];
+                d[3] = v[3];
             } else {
                 const int k = slot / (R / 4), r = (slot % (R / 4)) * 4;
-                *reinterpret_cast<f32x4*>(lds + L::addr(r, k)) = s.v[i];   // row stride is a multiple of 16 B
+                *reinterpret_cast<f32x4*>(lds + L::addr(r, k)) = v;   // row stride is a multiple of 16 B
             }
         }
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, bool QUAD>
 __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -169,16 +187,33 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Epilogue operands do not depend on the product: bias and (for beta != 0) the old C tile are asked for here,
+    // clamped and unpredicated, and are long back when the K loop ends.
+    const bool rmw = !a.atomic && a.beta != 0.f && (ks == 0 || a.sK != 0);
+    float bv[NI], cold[MI][NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = min(n0 + wc * WN + j * 16 + l15, a.N - 1);
+        bv[j] = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cold[i][j][r] = 0.f;
+                if (rmw) cold[i][j][r] = C[(long)min(m0 + wr * WM + i * 16 + l4 * 4 + r, a.M - 1) * a.ldc + col];
+            }
+    }
+
     const int nk = kend > kbeg ? (kend - kbeg + KT - 1) / KT : 0;
     Slab<BM> ra0, ra1;
     Slab<BN> rb0, rb1;
     if (nk > 0) {
-        slab_load<BM, !TA>(A, a.lda, m0, kbeg, a.M, kend, a.vecA, ra0);
-        slab_load<BN, TB>(B, a.ldb, n0, kbeg, a.N, kend, a.vecB, rb0);
+        slab_load<BM, !TA, QUAD>(A, a.lda, m0, kbeg, a.M, kend, ra0);
+        slab_load<BN, TB, QUAD>(B, a.ldb, n0, kbeg, a.N, kend, rb0);
     }
     if (nk > 1) {
-        slab_load<BM, !TA>(A, a.lda, m0, kbeg + KT, a.M, kend, a.vecA, ra1);
-        slab_load<BN, TB>(B, a.ldb, n0, kbeg + KT, a.N, kend, a.vecB, rb1);
+        slab_load<BM, !TA, QUAD>(A, a.lda, m0, kbeg + KT, a.M, kend, ra1);
+        slab_load<BN, TB, QUAD>(B, a.ldb, n0, kbeg + KT, a.N, kend, rb1);
     }
 
     auto compute = [&]() {
@@ -198,22 +233,22 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
     };
 
     for (int kt = 0; kt < nk; kt += 2) {
-        slab_store<BM, !TA>(As, ra0);
-        slab_store<BN, TB>(Bs, rb0);
+        slab_store<BM, !TA, QUAD>(As, ra0, m0, kbeg + kt * KT, a.M, kend);
+        slab_store<BN, TB, QUAD>(Bs, rb0, n0, kbeg + kt * KT, a.N, kend);
         __syncthreads();
         if (kt + 2 < nk) {
-            slab_load<BM, !TA>(A, a.lda, m0, kbeg + (kt + 2) * KT, a.M, kend, a.vecA, ra0);
-            slab_load<BN, TB>(B, a.ldb, n0, kbeg + (kt + 2) * KT, a.N, kend, a.vecB, rb0);
+            slab_load<BM, !TA, QUAD>(A, a.lda, m0, kbeg + (kt + 2) * KT, a.M, kend, ra0);
+            slab_load<BN, TB, QUAD>(B, a.ldb, n0, kbeg + (kt + 2) * KT, a.N, kend, rb0);
         }
         compute();
         __syncthreads();
         if (kt + 1 < nk) {
-            slab_store<BM, !TA>(As, ra1);
-            slab_store<BN, TB>(Bs, rb1);
+            slab_store<BM, !TA, QUAD>(As, ra1, m0, kbeg + (kt + 1) * KT, a.M, kend);
+            slab_store<BN, TB, QUAD>(Bs, rb1, n0, kbeg + (kt + 1) * KT, a.N, kend);
             __syncthreads();
             if (kt + 3 < nk) {
-                slab_load<BM, !TA>(A, a.lda, m0, kbeg + (kt + 3) * KT, a.M, kend, a.vecA, ra1);
-                slab_load<BN, TB>(B, a.ldb, n0, kbeg + (kt + 3) * KT, a.N, kend, a.vecB, rb1);
+                slab_load<BM, !TA, QUAD>(A, a.lda, m0, kbeg + (kt + 3) * KT, a.M, kend, ra1);
+                slab_load<BN, TB, QUAD>(B, a.ldb, n0, kbeg + (kt + 3) * KT, a.N, kend, rb1);
             }
             compute();
             __syncthreads();
@@ -236,7 +271,7 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
                     unsigned short h[4], m[4], l[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float v = (row0 + r < a.M) ? a.alpha * acc[i][j][r] + (a.bias ? a.bias[col] : 0.f) : 0.f;
+                        const float v = (row0 + r < a.M) ? a.alpha * acc[i][j][r] + bv[j] : 0.f;
                         bf16_split3(v, h[r], m[r], l[r]);
                     }
                     const long o = vs_index(0, a.split_ct, a.split_k8, vc >> 4, row0 >> 3, vc & 15, row0 & 7);
@@ -247,7 +282,6 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
                     *reinterpret_cast<u16x4*>(vb + o + 2 * pl) = (u16x4){l[0], l[1], l[2], l[3]};
                 }
             }
-            const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wr * WM + i * 16 + l4 * 4 + r;
@@ -257,8 +291,8 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
                     atomicAdd(cp, a.alpha * acc[i][j][r]);
                     continue;
                 }
-                float v = a.alpha * acc[i][j][r] + bv;
-                if (a.beta != 0.f && (ks == 0 || a.sK != 0)) v += a.beta * (*cp);
+                float v = a.alpha * acc[i][j][r] + bv[j];
+                if (rmw) v += a.beta * cold[i][j][r];
                 if (a.act == 1) v = fmaxf(v, 0.f);
                 *cp = v;
             }
@@ -287,15 +321,23 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmGroupArgs g) {
 #pragma unroll
     for (int i = 1; i < GEMM_GROUP_MAX; ++i)
         if (i < g.count && (int)blockIdx.x >= g.tile0[i]) pi = i;
-    const GemmArgs& a = g.p[pi];
+    const GemmArgs a = g.p[pi];      // a copy: one burst of scalar loads instead of a kernarg read per use
     const int tile = blockIdx.x - g.tile0[pi];
+    // 16-byte operand loads need four elements along each operand's contiguous dimension
+    const bool quad = (a.tA ? a.M : a.K) >= 4 && (a.tB ? a.K : a.N) >= 4;
+#define DP_GEMM_BODY(TA, TB)                                                          \
+    do {                                                                              \
+        if (quad) gemm_body<BM, BN, WAVES_M, WAVES_N, TA, TB, true>(a, tile, lds);    \
+        else gemm_body<BM, BN, WAVES_M, WAVES_N, TA, TB, false>(a, tile, lds);        \
+    } while (0)
     if (a.tA) {
-        if (a.tB) gemm_body<BM, BN, WAVES_M, WAVES_N, true, true>(a, tile, lds);
-        else gemm_body<BM, BN, WAVES_M, WAVES_N, true, false>(a, tile, lds);
+        if (a.tB) DP_GEMM_BODY(true, true);
+        else DP_GEMM_BODY(true, false);
     } else {
-        if (a.tB) gemm_body<BM, BN, WAVES_M, WAVES_N, false, true>(a, tile, lds);
-        else gemm_body<BM, BN, WAVES_M, WAVES_N, false, false>(a, tile, lds);
+        if (a.tB) DP_GEMM_BODY(false, true);
+        else DP_GEMM_BODY(false, false);
     }
+#undef DP_GEMM_BODY
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -339,6 +381,14 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
         if (s.N > maxN) maxN = s.N;
     }
     if (g.count == 0) return;
+    static const bool trace = getenv("DP_GEMM_TRACE") != nullptr;   // host-side shape log, one line per launch
+    if (trace) {
+        fprintf(stderr, "bgemm batch=%d ksplit=%d:", batch, ksplit);
+        for (int i = 0; i < g.count; ++i)
+            fprintf(stderr, " [%dx%dx%d %c%c%s%s]", g.p[i].M, g.p[i].N, g.p[i].K, g.p[i].tA ? 'T' : 'N',
+                    g.p[i].tB ? 'T' : 'N', d[i].nosplit ? " nosplit" : "", d[i].atomic ? " atomic" : "");
+        fprintf(stderr, "\n");
+    }
     // Largest tile that still gives >= TARGET workgroups (256 CUs x 2); smallest tile otherwise.
     static const long TARGET = [] {
         const char* e = getenv("DP_GEMM_TARGET_WGS");   // tuning knob: workgroups wanted before tiles grow
