@@ -256,6 +256,8 @@ struct RownormBwdArgs {
 };
 // grid (chunks, B): a workgroup owns a contiguous chunk of rows of ONE graph, so the column sums of dU
 // (the bias gradients, db = sum_rows dU) can be accumulated in LDS and leave as one partial per workgroup.
+// NK > 0: group widths up to 16 NK, the row's operands live in registers (see the item loop); NK == 0: any width.
+template <int NK>
 __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float colsum[];
     const int tl = threadIdx.x & 15;
@@ -280,6 +282,61 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
         const int w = a.g.w[g];
         const float* dx = a.dx.p[g] + row * a.dx.ld[g];
         const float* y = a.y.p[g] + row * a.y.ld[g];
+        if (NK > 0) {
+            // ---- every global read of the item goes out here, clamped and unpredicated: the row is one memory
+            // round trip instead of five dependent ones (statistics -> row -> row again)
+            const float* xh = a.has_bn ? a.xhat.p[g] + row * a.xhat.ld[g] : dx;
+            float dxv[NK > 0 ? NK : 1], yv[NK > 0 ? NK : 1], xhv[NK > 0 ? NK : 1];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int cc = min(tl + 16 * k, w - 1);
+                dxv[k] = dx[cc];
+                yv[k] = y[cc];
+                xhv[k] = xh[cc];
+            }
+            const float rstd_l = (a.has_bn ? a.stats : dx)[a.has_bn ? ((long)node * a.g.G + g) * 2 + 1 : 0];
+            const float inv_l = (a.normalize ? a.invn : dx)[a.normalize ? row * a.g.G + g : 0];
+            float s0 = 0.f, s1 = 0.f;
+            {
+                const long pstride = (long)a.n * a.g.G * 2;
+                const float* p = (a.has_bn ? a.part2 : dx) + (a.has_bn ? ((long)node * a.g.G + g) * 2 : 0);
+                const int nb = a.has_bn ? a.B : 0;
+                for (int bb = tl; bb < nb; bb += 16) {
+                    s0 += p[bb * pstride];
+                    s1 += p[bb * pstride + 1];
+                }
+            }
+            // ---- arithmetic
+            const float cnt = (float)a.B * (float)w;
+            const float rstd = a.has_bn ? rstd_l : 1.f;
+            const float m0 = a.has_bn ? team_sum(s0) / cnt : 0.f;
+            const float m1 = a.has_bn ? team_sum(s1) / cnt : 0.f;
+            const float inv = a.normalize ? inv_l : 1.f;
+            const bool project = a.normalize && (inv < 1.0f / L2_EPS);
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                float d = dxv[k];
+                if (a.has_bn) d = rstd * (d - m0 - xhv[k] * m1);
+                if (a.has_relu) d = yv[k] > 0.f ? d : 0.f;
+                if (tl + 16 * k >= w) d = 0.f;
+                dxv[k] = d;
+                dot += d * yv[k];
+            }
+            dot = team_sum(dot);
+            float* du = a.dU + row * a.ldu + a.g.c0[g];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int c = tl + 16 * k;
+                if (c < w) {
+                    const float v = project ? inv * (dxv[k] - yv[k] * dot) : inv * dxv[k];
+                    du[c] = v;
+                    if (a.want_bias) mysum[a.g.c0[g] + c] += v;
+                    if (a.vs) tile8[(node - r0) * ct + a.g.c0[g] + c] = v;
+                }
+            }
+            continue;
+        }
         const float* xh = a.has_bn ? a.xhat.p[g] + row * a.xhat.ld[g] : nullptr;
         float rstd = 1.f, m0 = 0.f, m1 = 0.f;
         if (a.has_bn) {
@@ -367,8 +424,14 @@ void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const flo
     const int ct = g.c0[g.G - 1] + g.w[g.G - 1];
     RownormBwdArgs a{dx, xhat, y, invn, stats, part2, g, dU, ldu, db, want, vs, (ct + 15) / 16, ((n + 31) / 32) * 4,
                      B, n, 8, has_relu, has_bn, normalize};
-    hipLaunchKernelGGL(k_rownorm_bwd, dim3(rownorm_bwd_chunks(n), B), dim3(256),
-                       ((want ? 16 : 0) + (vs ? 8 : 0)) * ct * sizeof(float), q.stream, a);
+    const int maxw = g.G == 2 && g.w[1] > g.w[0] ? g.w[1] : g.w[0];
+    const dim3 grid(rownorm_bwd_chunks(n), B);
+    const size_t lds = ((want ? 16 : 0) + (vs ? 8 : 0)) * ct * sizeof(float);
+    if (maxw <= 32) hipLaunchKernelGGL(k_rownorm_bwd<2>, grid, dim3(256), lds, q.stream, a);
+    else if (maxw <= 64) hipLaunchKernelGGL(k_rownorm_bwd<4>, grid, dim3(256), lds, q.stream, a);
+    else if (maxw <= 128) hipLaunchKernelGGL(k_rownorm_bwd<8>, grid, dim3(256), lds, q.stream, a);
+    else if (maxw <= 256) hipLaunchKernelGGL(k_rownorm_bwd<16>, grid, dim3(256), lds, q.stream, a);
+    else hipLaunchKernelGGL(k_rownorm_bwd<0>, grid, dim3(256), lds, q.stream, a);
     q.check_launch("rownorm_bwd");
 }
 
