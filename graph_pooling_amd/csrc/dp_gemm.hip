@@ -45,9 +45,40 @@ struct GemmArgs {
     int atomic;       // 1: ranges add into C with float atomics (C pre-zeroed / accumulated into; no bias/act)
     unsigned short* split_out;            // optional 3-plane bf16 copy of C (see GemmDesc)
     int split_ct, split_k8, split_c0;
+    int stamp_slot;   // diagnostic build only
 };
 
 constexpr int KT = 32;
+
+#ifdef DP_STAMP
+// Diagnostic build only (csrc/build.sh with DP_STAMP=1, tools/gemm_stamps.py): per launch slot, the earliest start and
+// the latest end over all workgroups plus the phases of workgroup (0,0), on the 100 MHz realtime counter (the shader
+// clock differs between XCDs).  No stamp executes in the product build.
+__device__ unsigned long long g_gemm_stamps[64][8];
+// (one atomic per workgroup on a shared word distorts everything: only the first and the last workgroup stamp)
+#define GEMM_STAMP_MIN(slot)                                                                   \
+    do {                                                                                       \
+        if (blockIdx.x == 0 && blockIdx.y == 0) g_gemm_stamps[slot][0] = wall_clock64();       \
+    } while (0)
+#define GEMM_STAMP_MAX(slot)                                                                   \
+    do {                                                                                       \
+        if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) g_gemm_stamps[slot][1] = wall_clock64(); \
+    } while (0)
+#define GEMM_STAMP(slot, i)                                                                               \
+    do {                                                                                                  \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_gemm_stamps[slot][i] = wall_clock64(); \
+    } while (0)
+#else
+#define GEMM_STAMP_MIN(slot) \
+    do {                     \
+    } while (0)
+#define GEMM_STAMP_MAX(slot) \
+    do {                     \
+    } while (0)
+#define GEMM_STAMP(slot, i) \
+    do {                    \
+    } while (0)
+#endif
 
 template <int R, bool KCONTIG>
 struct LdsImage {
@@ -205,17 +236,19 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
     }
 
     const int nk = kend > kbeg ? (kend - kbeg + KT - 1) / KT : 0;
-    Slab<BM> ra0, ra1;
-    Slab<BN> rb0, rb1;
-    if (nk > 0) {
-        slab_load<BM, !TA, QUAD>(A, a.lda, m0, kbeg, a.M, kend, ra0);
-        slab_load<BN, TB, QUAD>(B, a.ldb, n0, kbeg, a.N, kend, rb0);
-    }
-    if (nk > 1) {
-        slab_load<BM, !TA, QUAD>(A, a.lda, m0, kbeg + KT, a.M, kend, ra1);
-        slab_load<BN, TB, QUAD>(B, a.ldb, n0, kbeg + KT, a.N, kend, rb1);
-    }
+    // Two K slabs of each operand are in flight ahead of the multiply.  (Four -- every slab of the 1-4 slab ranges the
+    // model hands over -- measured no better: DD 0.376 vs 0.371 ms per step, and 184 VGPRs on the 128x32 tile.)
+    constexpr int DEPTH = 2;
+    Slab<BM> ra[DEPTH];
+    Slab<BN> rb[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < nk) {
+            slab_load<BM, !TA, QUAD>(A, a.lda, m0, kbeg + d * KT, a.M, kend, ra[d]);
+            slab_load<BN, TB, QUAD>(B, a.ldb, n0, kbeg + d * KT, a.N, kend, rb[d]);
+        }
 
+    GEMM_STAMP(a.stamp_slot, 3);     // operand and epilogue loads issued
     auto compute = [&]() {
 #pragma unroll
         for (int kk = 0; kk < KT; kk += 4) {
@@ -232,29 +265,25 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
         }
     };
 
-    for (int kt = 0; kt < nk; kt += 2) {
-        slab_store<BM, !TA, QUAD>(As, ra0, m0, kbeg + kt * KT, a.M, kend);
-        slab_store<BN, TB, QUAD>(Bs, rb0, n0, kbeg + kt * KT, a.N, kend);
-        __syncthreads();
-        if (kt + 2 < nk) {
-            slab_load<BM, !TA, QUAD>(A, a.lda, m0, kbeg + (kt + 2) * KT, a.M, kend, ra0);
-            slab_load<BN, TB, QUAD>(B, a.ldb, n0, kbeg + (kt + 2) * KT, a.N, kend, rb0);
-        }
-        compute();
-        __syncthreads();
-        if (kt + 1 < nk) {
-            slab_store<BM, !TA, QUAD>(As, ra1, m0, kbeg + (kt + 1) * KT, a.M, kend);
-            slab_store<BN, TB, QUAD>(Bs, rb1, n0, kbeg + (kt + 1) * KT, a.N, kend);
-            __syncthreads();
-            if (kt + 3 < nk) {
-                slab_load<BM, !TA, QUAD>(A, a.lda, m0, kbeg + (kt + 3) * KT, a.M, kend, ra1);
-                slab_load<BN, TB, QUAD>(B, a.ldb, n0, kbeg + (kt + 3) * KT, a.N, kend, rb1);
+    for (int kt = 0; kt < nk; kt += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (kt + d < nk) {
+                if (kt + d > 0) __syncthreads();          // the previous slab's readers are done
+                slab_store<BM, !TA, QUAD>(As, ra[d], m0, kbeg + (kt + d) * KT, a.M, kend);
+                slab_store<BN, TB, QUAD>(Bs, rb[d], n0, kbeg + (kt + d) * KT, a.N, kend);
+                __syncthreads();
+                if (kt + d == 0) GEMM_STAMP(a.stamp_slot, 4);   // first slabs arrived and published
+                if (kt + d + DEPTH < nk) {
+                    slab_load<BM, !TA, QUAD>(A, a.lda, m0, kbeg + (kt + d + DEPTH) * KT, a.M, kend, ra[d]);
+                    slab_load<BN, TB, QUAD>(B, a.ldb, n0, kbeg + (kt + d + DEPTH) * KT, a.N, kend, rb[d]);
+                }
+                compute();
             }
-            compute();
-            __syncthreads();
         }
     }
 
+    GEMM_STAMP(a.stamp_slot, 5);     // K loop done
     // C/D map of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -297,6 +326,7 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
                 *cp = v;
             }
         }
+    GEMM_STAMP(a.stamp_slot, 6);
 }
 
 // One launch, up to GEMM_GROUP_MAX independent problems (same batch count): the workgroup finds its
@@ -304,6 +334,7 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
 struct GemmGroupArgs {
     const int* pred;     // non-null: run only when *pred != 0
     int count;
+    int stamp_slot;      // diagnostic build only
     int tile0[GEMM_GROUP_MAX + 1];
     GemmArgs p[GEMM_GROUP_MAX];
 };
@@ -317,11 +348,14 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmGroupArgs g) {
     __shared__ __attribute__((aligned(16))) float
         lds[cmax(lds_size<BM, true>(), lds_size<BM, false>()) + cmax(lds_size<BN, true>(), lds_size<BN, false>()) + 8];
     if (g.pred && __builtin_amdgcn_readfirstlane(*g.pred) == 0) return;
+    if (threadIdx.x == 0) GEMM_STAMP_MIN(g.stamp_slot);
+    GEMM_STAMP(g.stamp_slot, 2);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < GEMM_GROUP_MAX; ++i)
         if (i < g.count && (int)blockIdx.x >= g.tile0[i]) pi = i;
-    const GemmArgs a = g.p[pi];      // a copy: one burst of scalar loads instead of a kernarg read per use
+    GemmArgs a = g.p[pi];            // a copy: one burst of scalar loads instead of a kernarg read per use
+    a.stamp_slot = g.stamp_slot;
     const int tile = blockIdx.x - g.tile0[pi];
     // 16-byte operand loads need four elements along each operand's contiguous dimension
     const bool quad = (a.tA ? a.M : a.K) >= 4 && (a.tB ? a.K : a.N) >= 4;
@@ -338,6 +372,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmGroupArgs g) {
         else DP_GEMM_BODY(false, false);
     }
 #undef DP_GEMM_BODY
+    if (threadIdx.x == 0) GEMM_STAMP_MAX(g.stamp_slot);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -352,6 +387,17 @@ static void launch_tile(Seq& q, GemmGroupArgs& g, int batch) {
         total += ((mrows + BM - 1) / BM) * a.tilesN;
     }
     g.tile0[g.count] = total;
+#ifdef DP_STAMP
+    static int launch_no = 0;
+    g.stamp_slot = launch_no++ & 63;
+    {
+        unsigned long long init[8] = {~0ULL, 0, 0, 0, 0, 0, 0,
+                                      (unsigned long long)g.p[0].M | ((unsigned long long)g.p[0].N << 16) |
+                                          ((unsigned long long)g.p[0].K << 32) | ((unsigned long long)g.count << 56)};
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gemm_stamps), init, sizeof(init), g.stamp_slot * sizeof(init),
+                                     hipMemcpyHostToDevice, q.stream);
+    }
+#endif
     hipLaunchKernelGGL((bgemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(total, batch * g.p[0].gsplit), dim3(256), 0,
                        q.stream, g);
 }
@@ -421,5 +467,11 @@ void bgemm(Seq& q, const float* A, const float* B, float* C, const float* bias, 
     GemmDesc d{A, B, C, bias, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, alpha, beta, act, 0, 0, nullptr, 0, 0, 0};
     bgemm_group(q, &d, 1, batch, 1);
 }
+
+#ifdef DP_STAMP
+extern "C" __attribute__((visibility("default"))) int dp_debug_gemm_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 64 * 8);
+}
+#endif
 
 }  // namespace dp

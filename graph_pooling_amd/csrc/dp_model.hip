@@ -209,6 +209,8 @@ RowGroups groups_of(const LevelInfo& li, int l) {
 // big graphs need it to fill the chip, large batches do not.
 int node_ksplit(const dp_encoder_cfg& c) {
     if (c.B >= 64) return 1;
+    static const int force = getenv("DP_NODE_KSPLIT") ? atoi(getenv("DP_NODE_KSPLIT")) : 0;   // tuning knob
+    if (force >= 1 && force <= 8) return force;
     int ks = (c.N + 127) / 128;
     return ks < 1 ? 1 : (ks > 8 ? 8 : ks);
 }

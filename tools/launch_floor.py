@@ -1,5 +1,6 @@
 """Measure the per-kernel cost of tiny dependent kernels under hipGraph replay and in eager mode (no profiler)."""
-import time, torch
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graph_pooling_amd import _lib
 lib = _lib.load()
 B, Cc = 20, 6
