@@ -30,12 +30,21 @@ __device__ inline float lk_block_sum(float v, float* red) {
 template <int KT, int ROWS>
 __device__ inline void lk_stage(const float* Sb, int lds_ld, int r0, int n, int K, float* dst) {
     constexpr int KW = KT * 16, KP = KW + 2;
+    // loads first, selects and LDS writes after: a select right behind its load makes every load a round trip of
+    // its own (the first version: one `s_waitcnt vmcnt(0)` per element, 32 serial round trips in the forward kernel)
+    constexpr int NV = ROWS * KW / 256;
+    float v[NV];
 #pragma unroll
-    for (int m = 0; m < ROWS * KW / 256; ++m) {
+    for (int m = 0; m < NV; ++m) {
         const int e = threadIdx.x + 256 * m;
         const int i = e / KW, k = e % KW;
-        const float v = Sb[(long)min(r0 + i, n - 1) * lds_ld + min(k, K - 1)];
-        dst[i * KP + k] = (r0 + i < n && k < K) ? v : 0.f;
+        v[m] = Sb[(long)min(r0 + i, n - 1) * lds_ld + min(k, K - 1)];
+    }
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        const int e = threadIdx.x + 256 * m;
+        const int i = e / KW, k = e % KW;
+        dst[i * KP + k] = (r0 + i < n && k < K) ? v[m] : 0.f;
     }
 }
 
@@ -187,8 +196,7 @@ __global__ __launch_bounds__(256) void k_link_bwd(const float* S, int lds_ld, co
         for (int m = 0; m < NS; ++m) {
             const int e = threadIdx.x + 256 * m;
             const int i = e / KW, k = e % KW;
-            const float v = Sb[(long)min(c0 + i, n - 1) * lds_ld + min(k, K - 1)];
-            sc[m] = (c0 + i < n && k < K) ? v : 0.f;
+            sc[m] = Sb[(long)min(c0 + i, n - 1) * lds_ld + min(k, K - 1)];    // raw: zeroed when it is written to LDS
         }
 #pragma unroll
         for (int m = 0; m < NA; ++m) {
@@ -211,7 +219,8 @@ __global__ __launch_bounds__(256) void k_link_bwd(const float* S, int lds_ld, co
 #pragma unroll
         for (int m = 0; m < NS; ++m) {
             const int e = threadIdx.x + 256 * m;
-            Sc[(e / KW) * KP + e % KW] = sc[m];
+            const int i = e / KW, k = e % KW;
+            Sc[i * KP + k] = (c0 + i < n && k < K) ? sc[m] : 0.f;
         }
 #pragma unroll
         for (int m = 0; m < NA; ++m) {
