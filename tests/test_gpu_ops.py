@@ -125,6 +125,36 @@ def _packed_aggregate(lib, adj, V, C, trans, beta, U0):
     return Ud, int(flag[0])
 
 
+@pytest.mark.parametrize("B,n", [(2, 128), (3, 131), (2, 500), (1, 68), (2, 4)])
+def test_adj_pack_images_are_the_bf16_bits_and_their_transpose(lib, B, n):
+    """dp_adj_pack: P[b, r, c] = high 16 bits of A[b, r, c], Pt its transpose, rows padded with zeros to a multiple of
+    8 elements; the flag word is 0 iff every entry is bf16-exact.  Bit-exact (integer) comparison."""
+    g = torch.Generator().manual_seed(n)
+    vals = torch.tensor([0.0, 1.0, 0.5, -3.0])
+    adj = vals[torch.randint(0, 4, (B, n, n), generator=g)]
+    ld = (n + 7) // 8 * 8
+    nb = lib.dp_adj_pack_bytes(B, n)
+    assert nb >= B * n * ld * 2
+    for exact in (True, False):
+        a = adj.clone()
+        if not exact:
+            a[B - 1, n - 1, n - 2] = 1.0 + 2.0 ** -20          # needs the low mantissa bits
+        pk = torch.full((nb,), 0xAB, device="cuda", dtype=torch.uint8)
+        pkt = torch.full((nb,), 0xCD, device="cuda", dtype=torch.uint8)
+        flag = torch.full((64,), 7, device="cuda", dtype=torch.int32)
+        _lib.check(lib.dp_adj_pack(dev(a).data_ptr(), pk.data_ptr(), pkt.data_ptr(), flag.data_ptr(), B, n, S()))
+        bits = (a.contiguous().view(torch.int32) >> 16).to(torch.int16)
+        want = torch.zeros(B, n, ld, dtype=torch.int16)
+        want[:, :, :n] = bits
+        want_t = torch.zeros(B, n, ld, dtype=torch.int16)
+        want_t[:, :, :n] = bits.transpose(1, 2)
+        got = pk[:B * n * ld * 2].view(torch.int16).view(B, n, ld).cpu()
+        got_t = pkt[:B * n * ld * 2].view(torch.int16).view(B, n, ld).cpu()
+        assert torch.equal(got, want)
+        assert torch.equal(got_t, want_t)
+        assert (int(flag[0]) == 0) == exact
+
+
 @pytest.mark.parametrize("trans", [0, 1])
 @pytest.mark.parametrize("B,n,C", [(3, 128, 5), (20, 500, 40), (4, 500, 70), (2, 1024, 33), (2, 516, 128),
                                    (2, 200, 50), (3, 131, 17), (2, 512, 276), (1, 1024, 256), (2, 260, 130),
