@@ -522,6 +522,8 @@ struct SoftmaxFwdArgs {
     uint4* zero_p;
     long zero_n16;
 };
+// NK > 0: K <= 16 NK, the row's logits are read once and its exponentials computed once, both kept in registers.
+template <int NK>
 __global__ __launch_bounds__(256) void k_softmax_mask_fwd_plan(SoftmaxFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];      // [16][K]
     const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
@@ -538,18 +540,47 @@ __global__ __launch_bounds__(256) void k_softmax_mask_fwd_plan(SoftmaxFwdArgs a)
         const float* l = a.logits + row * a.ldl;
         float* s = a.S + row * a.lds;
         float* s2 = a.S2 ? a.S2 + row * a.lds : nullptr;
-        float m = -INFINITY;
-        for (int c = tl; c < K; c += 16) m = fmaxf(m, l[c]);
-        m = team_max(m);
-        float sum = 0.f;
-        for (int c = tl; c < K; c += 16) sum += expf(l[c] - m);
-        sum = team_sum(sum);
-        const float r = 1.f / sum;
-        for (int c = tl; c < K; c += 16) {
-            const float v = valid ? expf(l[c] - m) * r : 0.f;
-            s[c] = v;
-            if (s2) s2[c] = v;
-            tile[team * K + c] = v;
+        if (NK > 0) {
+            constexpr int NKK = NK > 0 ? NK : 1;
+            float lv[NKK];
+#pragma unroll
+            for (int k = 0; k < NKK; ++k) lv[k] = l[min(tl + 16 * k, K - 1)];
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < NKK; ++k) m = fmaxf(m, lv[k]);        // clamped duplicates do not change a max
+            m = team_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < NKK; ++k) {
+                lv[k] = expf(lv[k] - m);
+                sum += (tl + 16 * k < K) ? lv[k] : 0.f;
+            }
+            sum = team_sum(sum);
+            const float r = 1.f / sum;
+#pragma unroll
+            for (int k = 0; k < NKK; ++k) {
+                const int c = tl + 16 * k;
+                if (c < K) {
+                    const float v = valid ? lv[k] * r : 0.f;
+                    s[c] = v;
+                    if (s2) s2[c] = v;
+                    tile[team * K + c] = v;
+                }
+            }
+        } else {
+            float m = -INFINITY;
+            for (int c = tl; c < K; c += 16) m = fmaxf(m, l[c]);
+            m = team_max(m);
+            float sum = 0.f;
+            for (int c = tl; c < K; c += 16) sum += expf(l[c] - m);
+            sum = team_sum(sum);
+            const float r = 1.f / sum;
+            for (int c = tl; c < K; c += 16) {
+                const float v = valid ? expf(l[c] - m) * r : 0.f;
+                s[c] = v;
+                if (s2) s2[c] = v;
+                tile[team * K + c] = v;
+            }
         }
     } else {
         for (int c = tl; c < K; c += 16) tile[team * K + c] = 0.f;
@@ -593,8 +624,12 @@ void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, c
         }
         SoftmaxFwdArgs a{logits, ldl, S, lds, S2, num_nodes, n, K, vs, (K + 15) / 16, ((n + 31) / 32) * 4,
                          (uint4*)zero_p, (long)(zero_bytes / 16)};
-        hipLaunchKernelGGL(k_softmax_mask_fwd_plan, dim3((n + 15) / 16, B), dim3(256), (size_t)16 * K * sizeof(float),
-                           q.stream, a);
+        const dim3 grid((n + 15) / 16, B);
+        const size_t sm = (size_t)16 * K * sizeof(float);
+        if (K <= 64) hipLaunchKernelGGL(k_softmax_mask_fwd_plan<4>, grid, dim3(256), sm, q.stream, a);
+        else if (K <= 128) hipLaunchKernelGGL(k_softmax_mask_fwd_plan<8>, grid, dim3(256), sm, q.stream, a);
+        else if (K <= 256) hipLaunchKernelGGL(k_softmax_mask_fwd_plan<16>, grid, dim3(256), sm, q.stream, a);
+        else hipLaunchKernelGGL(k_softmax_mask_fwd_plan<0>, grid, dim3(256), sm, q.stream, a);
         q.check_launch("softmax_mask_fwd_plan");
         return;
     }
@@ -622,6 +657,9 @@ __global__ __launch_bounds__(256) void k_softmax_mask_bwd(const float* S, int ld
 }
 // Encoder-plan variant: grid (64-row chunks, B); also adds the column sums of dlogits (the assign_pred bias
 // gradient) of its rows to the graph's slab row with one float atomic per column and workgroup.
+// NK > 0: K <= 16 NK and RW of a team's four rows have every operand in flight at once and kept in registers (one
+// memory round trip per RW rows; row after row with two passes each it was eight).  NK == 0: any K.
+template <int NK, int RW>
 __global__ __launch_bounds__(256) void k_softmax_mask_bwd_plan(const float* S, int lds, const float* dS, int ldds,
                                                                float* dl, int ldl, int n, int K, float* dbias,
                                                                long dbias_stride, const float* dS2) {
@@ -631,19 +669,58 @@ __global__ __launch_bounds__(256) void k_softmax_mask_bwd_plan(const float* S, i
     float* mysum = colsum + team * K;
     for (int c = tl; c < K; c += 16) mysum[c] = 0.f;
     const int r0 = blockIdx.x * 64, r1 = min(n, r0 + 64);
-    for (int node = r0 + team; node < r1; node += 16) {
-        const long row = (long)b * n + node;
-        const float* s = S + row * lds;
-        const float* d = dS + row * ldds;
-        const float* d2 = dS2 ? dS2 + row * ldds : nullptr;     // second addend of the incoming gradient (same ld)
-        float dot = 0.f;
-        for (int c = tl; c < K; c += 16) dot += s[c] * (d[c] + (d2 ? d2[c] : 0.f));
-        dot = team_sum(dot);
-        float* o = dl + row * ldl;
-        for (int c = tl; c < K; c += 16) {
-            const float v = s[c] * (d[c] + (d2 ? d2[c] : 0.f) - dot);
-            o[c] = v;
-            mysum[c] += v;
+    if (NK > 0) {
+        constexpr int NKK = NK > 0 ? NK : 1;
+        for (int base = r0 + team; base < r1; base += 16 * RW) {
+            float sv[RW][NKK], dv[RW][NKK];
+            const float* d2base = dS2 ? dS2 : dS;            // a valid address either way: no branch around loads
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                const long row = (long)b * n + min(base + 16 * j, n - 1);
+#pragma unroll
+                for (int k = 0; k < NKK; ++k) {
+                    const int c = min(tl + 16 * k, K - 1);
+                    sv[j][k] = S[row * lds + c];
+                    const float x = dS[row * ldds + c], y = d2base[row * ldds + c];
+                    dv[j][k] = dS2 ? x + y : x;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                const int node = base + 16 * j;
+                float dot = 0.f;
+#pragma unroll
+                for (int k = 0; k < NKK; ++k) dot += (tl + 16 * k < K) ? sv[j][k] * dv[j][k] : 0.f;
+                dot = team_sum(dot);
+                if (node < r1) {
+                    float* o = dl + ((long)b * n + node) * ldl;
+#pragma unroll
+                    for (int k = 0; k < NKK; ++k) {
+                        const int c = tl + 16 * k;
+                        if (c < K) {
+                            const float v = sv[j][k] * (dv[j][k] - dot);
+                            o[c] = v;
+                            mysum[c] += v;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        for (int node = r0 + team; node < r1; node += 16) {
+            const long row = (long)b * n + node;
+            const float* s = S + row * lds;
+            const float* d = dS + row * ldds;
+            const float* d2 = dS2 ? dS2 + row * ldds : nullptr;     // second addend of the incoming gradient (same ld)
+            float dot = 0.f;
+            for (int c = tl; c < K; c += 16) dot += s[c] * (d[c] + (d2 ? d2[c] : 0.f));
+            dot = team_sum(dot);
+            float* o = dl + row * ldl;
+            for (int c = tl; c < K; c += 16) {
+                const float v = s[c] * (d[c] + (d2 ? d2[c] : 0.f) - dot);
+                o[c] = v;
+                mysum[c] += v;
+            }
         }
     }
     __syncthreads();
@@ -660,8 +737,16 @@ void softmax_mask_bwd(Seq& q, const float* S, int lds, const float* dS, int ldds
     if (!q.ok()) return;
     const long rows = (long)B * n;
     if (dbias && (size_t)16 * K * sizeof(float) <= 64 * 1024) {
-        hipLaunchKernelGGL(k_softmax_mask_bwd_plan, dim3((n + 63) / 64, B), dim3(256), (size_t)16 * K * sizeof(float),
-                           q.stream, S, lds, dS, ldds, dlogits, ldl, n, K, dbias, dbias_stride, dS2);
+        const dim3 grid((n + 63) / 64, B);
+        const size_t sm = (size_t)16 * K * sizeof(float);
+#define DP_SMB(NK, RW)                                                                                            \
+    hipLaunchKernelGGL((k_softmax_mask_bwd_plan<NK, RW>), grid, dim3(256), sm, q.stream, S, lds, dS, ldds, dlogits, \
+                       ldl, n, K, dbias, dbias_stride, dS2)
+        if (K <= 64) DP_SMB(4, 4);
+        else if (K <= 128) DP_SMB(8, 2);
+        else if (K <= 256) DP_SMB(16, 1);
+        else DP_SMB(0, 1);
+#undef DP_SMB
         q.check_launch("softmax_mask_bwd_plan");
         return;
     }
