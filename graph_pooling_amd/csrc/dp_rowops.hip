@@ -141,6 +141,8 @@ __global__ __launch_bounds__(256) void k_bn_finalize(BnApplyArgs a) {
         a.stats[it * 2 + 1] = 1.0f / sqrtf(var + BN_EPS);
     }
 }
+// NK > 0: group widths <= 16 NK; the row is asked for BEFORE the statistics are reduced, not after.
+template <int NK>
 __global__ __launch_bounds__(256) void k_bn_apply_fwd(BnApplyArgs a) {
     const int tl = threadIdx.x & 15;
     const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -151,20 +153,37 @@ __global__ __launch_bounds__(256) void k_bn_apply_fwd(BnApplyArgs a) {
         const int g = (int)(it % a.g.G);
         const int node = (int)(row % a.n);
         const int w = a.g.w[g];
+        const float* y = a.Y + row * a.ldy + a.g.c0[g];
+        constexpr int NKK = NK > 0 ? NK : 1;
+        float yv[NKK];
+        if (NK > 0) {
+#pragma unroll
+            for (int k = 0; k < NKK; ++k) yv[k] = y[min(tl + 16 * k, w - 1)];
+        }
         float mu = 0.f, rstd = 1.f;
         if (a.part && a.stats_ready) {
             mu = a.stats[((long)node * a.g.G + g) * 2];
             rstd = a.stats[((long)node * a.g.G + g) * 2 + 1];
         } else if (a.part) {
+            // B <= 32 here (larger batches come with finished statistics): a lane's two partial pairs are read once
             const long pstride = (long)a.n * a.g.G * 2;
             const float* p = a.part + ((long)node * a.g.G + g) * 2;
+            float pm[2], pq[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long o = (long)min(tl + 16 * u, a.B - 1) * pstride;
+                pm[u] = p[o];
+                pq[u] = p[o + 1];
+            }
             float sm = 0.f;
-            for (int b = tl; b < a.B; b += 16) sm += p[b * pstride];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) sm += (tl + 16 * u < a.B) ? pm[u] : 0.f;
             mu = team_sum(sm) / (float)a.B;
             float s2 = 0.f;
-            for (int b = tl; b < a.B; b += 16) {
-                const float d = p[b * pstride] - mu;
-                s2 += p[b * pstride + 1] + (float)w * d * d;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float d = pm[u] - mu;
+                s2 += (tl + 16 * u < a.B) ? pq[u] + (float)w * d * d : 0.f;
             }
             const float var = team_sum(s2) / ((float)a.B * (float)w);
             rstd = 1.0f / sqrtf(var + BN_EPS);
@@ -173,11 +192,19 @@ __global__ __launch_bounds__(256) void k_bn_apply_fwd(BnApplyArgs a) {
                 a.stats[((long)node * a.g.G + g) * 2 + 1] = rstd;
             }
         }
-        const float* y = a.Y + row * a.ldy + a.g.c0[g];
         float* x = a.xout.p[g] + row * a.xout.ld[g];
-        for (int c = tl; c < w; c += 16) {
-            const float v = a.relu ? fmaxf(y[c], 0.f) : y[c];
-            x[c] = (v - mu) * rstd;
+        if (NK > 0) {
+#pragma unroll
+            for (int k = 0; k < NKK; ++k) {
+                const int c = tl + 16 * k;
+                const float v = a.relu ? fmaxf(yv[k], 0.f) : yv[k];
+                if (c < w) x[c] = (v - mu) * rstd;
+            }
+        } else {
+            for (int c = tl; c < w; c += 16) {
+                const float v = a.relu ? fmaxf(y[c], 0.f) : y[c];
+                x[c] = (v - mu) * rstd;
+            }
         }
     }
 }
@@ -190,7 +217,12 @@ void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* part, float* sta
         q.check_launch("bn_finalize");
         a.stats_ready = 1;
     }
-    hipLaunchKernelGGL(k_bn_apply_fwd, dim3(team_grid((long)B * n * g.G)), dim3(256), 0, q.stream, a);
+    const int maxw = g.G == 2 && g.w[1] > g.w[0] ? g.w[1] : g.w[0];
+    const dim3 grid(team_grid((long)B * n * g.G));
+    if (maxw <= 32) hipLaunchKernelGGL(k_bn_apply_fwd<2>, grid, dim3(256), 0, q.stream, a);
+    else if (maxw <= 64) hipLaunchKernelGGL(k_bn_apply_fwd<4>, grid, dim3(256), 0, q.stream, a);
+    else if (maxw <= 128) hipLaunchKernelGGL(k_bn_apply_fwd<8>, grid, dim3(256), 0, q.stream, a);
+    else hipLaunchKernelGGL(k_bn_apply_fwd<0>, grid, dim3(256), 0, q.stream, a);
     q.check_launch("bn_apply_fwd");
 }
 
