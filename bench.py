@@ -186,7 +186,7 @@ def roofline_probe(w, device, iters=200):
     return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                 kernel=(f"k_aggregate_wide<{ct}>" if packed and B * ((N + 127) // 128) >= 512
-                        else f"k_aggregate<false,{ct},{32 if B * ((N + 31) // 32) >= 256 else 16}>")
+                        else f"k_aggregate<false,{ct},{32 if B * ((N + 31) // 32) >= 256 else 16},4>")
                 + (" bf16-packed A x 3-plane bf16 V (exact)" if packed else " fp32 panel")
                 + " — level-0 aggregation A·[XW_e|XW_a]",
                 us_per_launch=round(us, 2), algorithmic_bytes=bytes_alg,
