@@ -30,6 +30,31 @@ __device__ inline void head_stage(float* dst, const float* src, int cnt) {
     }
 }
 
+// Split form of head_stage: `issue` asks for round `e0` of a segment (16 elements per thread, clamped addresses, gather
+// through idx), `commit` writes it to LDS.  Several segments are issued before the first commit, so their loads share
+// one memory round trip; segments longer than one round finish with stage_rest.
+template <int NT, typename Idx>
+__device__ __forceinline__ void stage_issue(float (&t)[16], const float* src, int cnt, int e0, Idx idx) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = src[idx(min(e0 + u * NT + (int)threadIdx.x, cnt - 1))];
+}
+template <int NT>
+__device__ __forceinline__ void stage_commit(float* dst, const float (&t)[16], int cnt, int e0) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int i = e0 + u * NT + (int)threadIdx.x;
+        if (i < cnt) dst[i] = t[u];
+    }
+}
+template <int NT, typename Idx>
+__device__ inline void stage_rest(float* dst, const float* src, int cnt, Idx idx) {
+    for (int e0 = NT * 16; e0 < cnt; e0 += NT * 16) {
+        float t[16];
+        stage_issue<NT>(t, src, cnt, e0, idx);
+        stage_commit<NT>(dst, t, cnt, e0);
+    }
+}
+
 struct HeadSizes {
     int wtot, btot, mx, hsum;      // weight floats, bias floats, widest layer, sum of dims[0..L]
 };
@@ -72,20 +97,51 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
         for (int u = 0; u < RU; ++u) zv[u] = zc[(long)min(wave + 4 * u, a.n - 1) * a.ldz];
     }
     // (2) ... then the weights, biases and lower-level features stream into LDS behind them
+    //     The first round of layer i+1 (and of the features) is in flight while layer i's is committed, so the
+    //     staging is about as many round trips as the longest segment has rounds, not their sum.
     {
+        const auto ident = [](int e) { return e; };
+        float tf[16], tw[16], tb[16];
+        stage_issue<256>(tf, feat, a.dims[0], 0, ident);
         int wo = 0, bo = 0;
-        for (int i = 0; i < a.n_pred; ++i) {
-            const int cnt = a.dims[i] * a.dims[i + 1];
-            const float* W = a.params + a.w_off[i];
-            head_stage<256>(Wl + wo, W, cnt);
-            for (int e = threadIdx.x; e < a.dims[i + 1]; e += 256)
-                bl[bo + e] = a.b_off[i] >= 0 ? a.params[a.b_off[i] + e] : 0.f;
-            wo += cnt;
-            bo += a.dims[i + 1];
+        {
+            const int cnt0 = a.dims[0] * a.dims[1];
+            stage_issue<256>(tw, a.params + a.w_off[0], cnt0, 0, ident);
         }
+        for (int i = 0; i < a.n_pred; ++i) {
+            const int cnt = a.dims[i] * a.dims[i + 1], bc = a.dims[i + 1];
+            const float* W = a.params + a.w_off[i];
+            const float* bsrc = a.b_off[i] >= 0 ? a.params + a.b_off[i] : W;      // a valid address either way
+            stage_issue<256>(tb, bsrc, bc, 0, ident);
+            float tn[16];                                                          // next layer's first round
+            const bool more = i + 1 < a.n_pred;
+            if (more) stage_issue<256>(tn, a.params + a.w_off[i + 1], a.dims[i + 1] * a.dims[i + 2], 0, ident);
+            stage_commit<256>(Wl + wo, tw, cnt, 0);
+            if (a.b_off[i] < 0) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) tb[u] = 0.f;
+            }
+            stage_commit<256>(bl + bo, tb, bc, 0);
+            stage_rest<256>(Wl + wo, W, cnt, ident);
+            if (a.b_off[i] >= 0) stage_rest<256>(bl + bo, bsrc, bc, ident);
+            else
+                for (int e = 4096 + threadIdx.x; e < bc; e += 256) bl[bo + e] = 0.f;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) tw[u] = tn[u];
+            }
+            wo += cnt;
+            bo += bc;
+        }
+        // features of the lower levels (the readout columns of this level are produced below)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = u * 256 + (int)threadIdx.x;
+            if (k < a.dims[0] && (!a.Z || k < a.featoff || k >= a.featoff + a.rw)) h0[k] = tf[u];
+        }
+        for (int k = 4096 + threadIdx.x; k < a.dims[0]; k += 256)
+            if (!a.Z || k < a.featoff || k >= a.featoff + a.rw) h0[k] = feat[k];
     }
-    for (int k = threadIdx.x; k < a.dims[0]; k += 256)
-        if (!a.Z || k < a.featoff || k >= a.featoff + a.rw) h0[k] = feat[k];
     if (a.Z) {
         // unmasked max over the nodes of the last level; ties -> lowest row (torch CPU max).  Four row groups x 64
         // columns per pass, combined through LDS.
@@ -208,21 +264,53 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
     float* F0 = W0 + d1 * HEAD_SLICE;             // [B][ks] slice of the features
     float* g0 = F0 + B * HEAD_SLICE;              // gradient ping / pong [B x mx]
     float* g1 = g0 + (long)B * mx;
+    int win[2] = {-1, -1};                        // max-readout winner rows of this thread's first two features
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = min((int)threadIdx.x + 256 * it, B * ks - 1);
+        const int b = e / ks, k = k0 + e % ks;
+        if (a.n_levels > 0) {                     // uniform; the load itself is unconditional (no branch, no select:
+            const int* src = a.lv[0].argmax;      // a feature outside every level reads a valid dummy it never uses)
+            for (int lv = 0; lv < a.n_levels; ++lv) {
+                const int f = k - a.lv[lv].featoff;
+                if (f >= 0 && f < a.lv[lv].rw) src = a.lv[lv].argmax + (long)b * a.lv[lv].lda + f;
+            }
+            win[it] = *src;
+        }
+    }
     {
+        // first-layer slice, feature slice and incoming gradient: asked for first, committed after the upper layers'
+        // operands, so the whole staging is about two memory round trips (it was eight: one per loop)
+        const auto ident = [](int e) { return e; };
+        const auto slice = [=](int e) { return (long)(e >> 4) * d0 + k0 + min(e & 15, ks - 1); };   // [rows][HEAD_SLICE]
+        static_assert(HEAD_SLICE == 16, "slice index math");
+        const float* W0g = a.h.params + a.h.w_off[0];
+        const float* F0g = a.h.hid[0];
+        const int cW0 = d1 * HEAD_SLICE, cF0 = B * HEAD_SLICE, cG = B * a.h.dims[L];
+        float tw0[16], tf0[16], tg[16];
+        stage_issue<256>(tw0, W0g, cW0, 0, slice);
+        stage_issue<256>(tf0, F0g, cF0, 0, slice);
+        stage_issue<256>(tg, a.d_ypred, cG, 0, ident);
         int wo = 0, ho = 0;
         for (int i = 1; i < L; ++i) {
-            const int cnt = a.h.dims[i] * a.h.dims[i + 1];
+            const int cnt = a.h.dims[i] * a.h.dims[i + 1], hc = B * a.h.dims[i];
             const float* W = a.h.params + a.h.w_off[i];
-            head_stage<256>(Wu + wo, W, cnt);
-            head_stage<256>(Hu + ho, a.h.hid[i], B * a.h.dims[i]);
+            float tw[16], th[16];
+            stage_issue<256>(tw, W, cnt, 0, ident);
+            stage_issue<256>(th, a.h.hid[i], hc, 0, ident);
+            stage_commit<256>(Wu + wo, tw, cnt, 0);
+            stage_commit<256>(Hu + ho, th, hc, 0);
+            stage_rest<256>(Wu + wo, W, cnt, ident);
+            stage_rest<256>(Hu + ho, a.h.hid[i], hc, ident);
             wo += cnt;
-            ho += B * a.h.dims[i];
+            ho += hc;
         }
-        const float* W = a.h.params + a.h.w_off[0];
-        for (int e = threadIdx.x; e < d1 * ks; e += 256) W0[(e / ks) * HEAD_SLICE + e % ks] = W[(long)(e / ks) * d0 + k0 + e % ks];
-        const float* f = a.h.hid[0];
-        for (int e = threadIdx.x; e < B * ks; e += 256) F0[(e / ks) * HEAD_SLICE + e % ks] = f[(long)(e / ks) * d0 + k0 + e % ks];
-        for (int e = threadIdx.x; e < B * a.h.dims[L]; e += 256) g0[e] = a.d_ypred[e];
+        stage_commit<256>(W0, tw0, cW0, 0);
+        stage_commit<256>(F0, tf0, cF0, 0);
+        stage_commit<256>(g0, tg, cG, 0);
+        stage_rest<256>(W0, W0g, cW0, slice);
+        stage_rest<256>(F0, F0g, cF0, slice);
+        stage_rest<256>(g0, a.d_ypred, cG, ident);
     }
     __syncthreads();
     float* go = g0;
@@ -279,7 +367,9 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
             a.grads[a.h.b_off[0] + j] = s;
         }
     // d(features) of the slice and its max-readout scatter: dZ[b, argmax, f] += dfeat  (dZ zero-initialised by the caller)
-    for (int e = threadIdx.x; e < B * ks; e += 256) {
+    // (a feature belongs to one level; its winner row was asked for at kernel start; dZ is zero on entry -- the caller's
+    // contract -- and every (graph, row, feature) is written by one thread, so the scatter is a plain store)
+    for (int e = threadIdx.x, it = 0; e < B * ks; e += 256, ++it) {
         const int b = e / ks, kk = e % ks, k = k0 + kk;
         float s = 0.f;
 #pragma unroll 8
@@ -288,8 +378,8 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
             const HeadBwdArgs::Level& t = a.lv[lv];
             const int f = k - t.featoff;
             if (f >= 0 && f < t.rw) {
-                const int r = t.argmax[(long)b * t.lda + f];
-                if (r >= 0) t.dZ[((long)b * t.n + r) * t.ldz + f] += s;
+                const int r = it == 0 ? win[0] : it == 1 ? win[1] : t.argmax[(long)b * t.lda + f];
+                if (r >= 0) t.dZ[((long)b * t.n + r) * t.ldz + f] = s;
             }
         }
     }
