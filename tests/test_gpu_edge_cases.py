@@ -92,3 +92,15 @@ def test_weighted_adjacency_takes_the_fp32_fallback_at_a_packed_size():
 
 def test_wide_hidden_dims():
     _run(2, 130, 10, 70, 3, 0.3, p=0.05)                 # C = 140 per joint layer: wide kernel + fused tail fallbacks
+
+
+@pytest.mark.parametrize("H,N,ratio", [
+    (40, 200, 0.5),       # widths in (32, 64], K = 100 in (64, 128]: the NK = 4 row kernels, softmax <8, 2>
+    (150, 96, 0.25),      # widths in (128, 256]: rownorm <16>, generic bn_apply
+    (260, 64, 0.25),      # widths > 256: the any-width row kernels
+    (12, 600, 0.5),       # K = 300 > 256: the any-K softmax kernels
+])
+def test_row_kernel_width_classes(H, N, ratio):
+    """The row kernels (rownorm backward, bn apply, the softmax plan pair) are compiled per width class with the row
+    held in registers; one configuration per class, against the oracle at fp32 tolerance."""
+    _run(2, N, 9, H, 3, ratio, p=0.05)
