@@ -37,7 +37,6 @@ struct GemmArgs {
     float alpha, beta;
     int act;
     int tilesN;
-    int vecA, vecB;   // operand may be read with 16-byte loads
     int tA, tB;
     int ksplit;       // K is cut into `ksplit` ranges handled by different workgroups
     int gsplit;       // ranges of the LAUNCH (blockIdx.y = b*gsplit + ks); a problem with ksplit < gsplit idles ks >= ksplit
@@ -402,8 +401,6 @@ static void launch_tile(Seq& q, GemmGroupArgs& g, int batch) {
                        q.stream, g);
 }
 
-static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
 void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
     if (!q.ok() || batch <= 0 || count <= 0) return;
     if (ksplit < 1) ksplit = 1;
@@ -420,10 +417,8 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
         if (s.M <= 0 || s.N <= 0) continue;
         GemmArgs& a = g.p[g.count++];
         a = GemmArgs{s.A, s.B, s.C, s.bias, s.M, s.N, s.K, s.lda, s.ldb, s.ldc, s.sA, s.sB, s.sC, s.alpha, s.beta,
-                     s.act, 0, 0, 0, s.tA ? 1 : 0, s.tB ? 1 : 0, s.nosplit ? 1 : ksplit, ksplit, s.sK, s.atomic,
+                     s.act, 0, s.tA ? 1 : 0, s.tB ? 1 : 0, s.nosplit ? 1 : ksplit, ksplit, s.sK, s.atomic,
                      s.split_out, s.split_ct, s.split_k8, s.split_c0};
-        a.vecA = aligned16(s.A) && (s.lda % 4 == 0) && (s.sA % 4 == 0);
-        a.vecB = aligned16(s.B) && (s.ldb % 4 == 0) && (s.sB % 4 == 0);
         if (s.N > maxN) maxN = s.N;
     }
     if (g.count == 0) return;

@@ -20,18 +20,18 @@ def close(a, b, rtol=1e-4, atol=1e-5):
     torch.testing.assert_close(a.float(), b.float(), rtol=rtol, atol=atol)
 
 
-def grads_close(model, ref_grads, rtol=2e-3, atol=2e-5):
+def grads_close(model, ref_grads, rtol=2e-3, atol=2e-5, scale_tol=2e-4):
     named = dict(model.named_parameters())
     assert set(named) == set(ref_grads), set(named) ^ set(ref_grads)
     for k, p in named.items():
         assert p.grad is not None, k
         g = ref_grads[k]
         scale = float(g.abs().max())
-        close(p.grad, g, rtol=rtol, atol=max(atol, 2e-4 * scale))
+        close(p.grad, g, rtol=rtol, atol=max(atol, scale_tol * scale))
 
 
 def _run(B, N, F_, H, Cc, ratio, *, linkpred=False, num_layers=3, pred_hidden=(50,), assign_input_dim=-1,
-         n_min=None, n_max=None, p=0.2, weighted=False, seed=3):
+         n_min=None, n_max=None, p=0.2, weighted=False, seed=3, scale_tol=2e-4):
     n_min = max(1, N // 8) if n_min is None else n_min
     x, adj, nn_, label = O.make_batch(B, N, F_, n_min=n_min, n_max=n_max, p=p, seed=seed, n_classes=Cc)
     if weighted:
@@ -57,7 +57,7 @@ def _run(B, N, F_, H, Cc, ratio, *, linkpred=False, num_layers=3, pred_hidden=(5
     close(ypred, yo)
     close(model.assign_tensor, inter["assign_0"], 1e-4, 1e-6)
     close(loss, lo, 1e-4, 1e-6)
-    grads_close(model, {k: v.grad for k, v in P.items()})
+    grads_close(model, {k: v.grad for k, v in P.items()}, scale_tol=scale_tol)
 
 
 def test_single_cluster():
@@ -103,4 +103,8 @@ def test_wide_hidden_dims():
 def test_row_kernel_width_classes(H, N, ratio):
     """The row kernels (rownorm backward, bn apply, the softmax plan pair) are compiled per width class with the row
     held in registers; one configuration per class, against the oracle at fp32 tolerance."""
-    _run(2, N, 9, H, 3, ratio, p=0.05)
+    # fp32 tolerance: 2e-3 relative, absolute floor 2e-3 of the tensor's largest gradient.  The floor is ten times the
+    # suite's usual one: these bias gradients are sums over up to 1200 rows (x 300 clusters) that nearly cancel, the
+    # oracle and the kernels add them in different orders (atomics, split-K; the K = 300 case moved between runs by
+    # 1.2e-4 on an element 50x below the tensor's maximum), and small elements carry that absolute error.
+    _run(2, N, 9, H, 3, ratio, p=0.05, scale_tol=2e-3)
