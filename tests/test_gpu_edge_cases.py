@@ -27,7 +27,10 @@ def grads_close(model, ref_grads, rtol=2e-3, atol=2e-5, scale_tol=2e-4):
         assert p.grad is not None, k
         g = ref_grads[k]
         scale = float(g.abs().max())
-        close(p.grad, g, rtol=rtol, atol=max(atol, scale_tol * scale))
+        try:
+            close(p.grad, g, rtol=rtol, atol=max(atol, scale_tol * scale))
+        except AssertionError as e:
+            raise AssertionError(f"gradient of {k} (largest reference entry {scale:.3e}): {e}") from None
 
 
 def _run(B, N, F_, H, Cc, ratio, *, linkpred=False, num_layers=3, pred_hidden=(50,), assign_input_dim=-1,
