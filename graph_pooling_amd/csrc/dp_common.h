@@ -140,7 +140,17 @@ struct GemmDesc {
     unsigned short* split_out;
     int split_ct, split_k8, split_c0;   // total column blocks, k8 groups, column offset of this problem in V
     int nosplit;   // this problem walks its whole K in one workgroup even when the launch is split-K (grouped siblings)
+    // deterministic split-K (instead of `atomic`): every K range stores its partial tile to fix_part
+    // ([batch][ksplit][M][N] floats), takes a ticket from fix_cnt (one zeroed int per (batch, 16x16 block row/col
+    // pair upper bound: see gemm_fix_counters)), and the LAST range to arrive adds the partials in range order and
+    // writes C.  Bit-reproducible, one launch, no workgroup ever waits for another.
+    float* fix_part;
+    int* fix_cnt;
 };
+// ints of fix_cnt a problem needs (an upper bound over every tile shape the launcher may pick)
+inline size_t gemm_fix_counters(int batch, int M, int N) {
+    return (size_t)batch * ((M + 15) / 16) * ((N + 15) / 16);
+}
 
 // hi/mid/lo bf16 planes with hi + mid + lo == v exactly (round-to-nearest-even at each step)
 __device__ inline void bf16_split3(float v, unsigned short& h, unsigned short& m, unsigned short& l) {

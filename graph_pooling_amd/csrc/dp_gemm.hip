@@ -44,6 +44,8 @@ struct GemmArgs {
     int atomic;       // 1: ranges add into C with float atomics (C pre-zeroed / accumulated into; no bias/act)
     unsigned short* split_out;            // optional 3-plane bf16 copy of C (see GemmDesc)
     int split_ct, split_k8, split_c0;
+    float* fix_part;                      // deterministic split-K (see GemmDesc)
+    int* fix_cnt;
     int stamp_slot;   // diagnostic build only
 };
 
@@ -204,7 +206,7 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
     const int kchunk = ((a.K + a.ksplit * KT - 1) / (a.ksplit * KT)) * KT;
     const int kbeg = ks * kchunk;
     const int kend = min(a.K, kbeg + kchunk);
-    if (kbeg >= kend && ks > 0 && a.sK == 0) return;   // nothing to add to a shared C
+    if (kbeg >= kend && ks > 0 && a.sK == 0 && !a.fix_part) return;   // nothing to add to a shared C
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -219,7 +221,7 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
 
     // Epilogue operands do not depend on the product: bias and (for beta != 0) the old C tile are asked for here,
     // clamped and unpredicated, and are long back when the K loop ends.
-    const bool rmw = !a.atomic && a.beta != 0.f && (ks == 0 || a.sK != 0);
+    const bool rmw = !a.atomic && a.beta != 0.f && (ks == 0 || a.sK != 0 || a.fix_part);
     float bv[NI], cold[MI][NI][4];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -283,6 +285,48 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
     }
 
     GEMM_STAMP(a.stamp_slot, 5);     // K loop done
+    if (a.fix_part && a.ksplit > 1) {
+        // ---- deterministic split-K: partial out, ticket, the last range sums all partials in range order
+        const long pstride = (long)a.M * a.N;
+        float* Pb = a.fix_part + (long)b * a.ksplit * pstride;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int col = n0 + wc * WN + j * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wr * WM + i * 16 + l4 * 4 + r;
+                    if (row < a.M && col < a.N)      // agent-scope (write-through) store: no cache flush needed later
+                        __hip_atomic_store(Pb + (long)ks * pstride + (long)row * a.N + col, acc[i][j][r],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        // the partial is at the device's coherence point once its stores have been acknowledged; a full fence
+        // (`__threadfence()`: L2 write-back + invalidate per workgroup) made this launch 70 us slower
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // (also: every wave is done reading the operand slabs)
+        int* ticket = reinterpret_cast<int*>(lds);
+        if (threadIdx.x == 0)
+            *ticket = atomicAdd(a.fix_cnt + (long)b * (((a.M + BM - 1) / BM) * a.tilesN) + tile, 1);
+        __syncthreads();
+        if (*ticket != a.ksplit - 1) return;               // uniform: somebody else arrives last
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int col = n0 + wc * WN + j * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = min(m0 + wr * WM + i * 16 + l4 * 4 + r, a.M - 1);
+                    const float* src = Pb + (long)row * a.N + min(col, a.N - 1);
+                    float v = 0.f;
+                    for (int k2 = 0; k2 < a.ksplit; ++k2)      // agent-scope loads: past this XCD's caches
+                        v += __hip_atomic_load(src + (long)k2 * pstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc[i][j][r] = v;
+                }
+            }
+    }
     // C/D map of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -418,7 +462,7 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
         GemmArgs& a = g.p[g.count++];
         a = GemmArgs{s.A, s.B, s.C, s.bias, s.M, s.N, s.K, s.lda, s.ldb, s.ldc, s.sA, s.sB, s.sC, s.alpha, s.beta,
                      s.act, 0, s.tA ? 1 : 0, s.tB ? 1 : 0, s.nosplit ? 1 : ksplit, ksplit, s.sK, s.atomic,
-                     s.split_out, s.split_ct, s.split_k8, s.split_c0};
+                     s.split_out, s.split_ct, s.split_k8, s.split_c0, s.fix_part, s.fix_cnt};
         if (s.N > maxN) maxN = s.N;
     }
     if (g.count == 0) return;

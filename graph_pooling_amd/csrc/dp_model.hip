@@ -615,18 +615,29 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
             // launch also zero-fills those outputs and writes the bf16 split of S for the packed A^T S pass.
             const int ksn = n >= 256 ? node_ksplit(c) : 1;
             const bool s_split = j == 0 && pkp && aggregate_packed_usable(io.adj, n, K);
+            // (deterministic split-K: partial tiles + tickets, the last range sums in range order -- float atomics
+            // here made X' and A' vary in the last bit from run to run, enough to flip a near-tied max-readout
+            // winner downstream and route its gradient to another row; the softmax launch zero-fills the tickets)
+            const size_t cnt_ints = ksn > 1 ? gemm_fix_counters(B, K, li.D) + gemm_fix_counters(B, K, K) : 0;
+            int* fix_cnt = ksn > 1 ? q.alloc<int>((cnt_ints + 63) & ~size_t(63)) : nullptr;
+            float* fix_part = ksn > 1 ? q.alloc<float>((size_t)B * ksn * K * (li.D + K)) : nullptr;
             softmax_mask_fwd(q, sc.logits, K, lv.S, K, nn_j, B, n, K, j == 0 ? assign_out : nullptr,
-                             s_split ? sc.vs : nullptr, ksn > 1 ? lv.Xn : nullptr,
-                             ksn > 1 ? align256((size_t)((char*)(lv.An + (size_t)B * K * K) - (char*)lv.Xn)) : 0);
+                             s_split ? sc.vs : nullptr, fix_cnt, ((cnt_ints + 63) & ~size_t(63)) * sizeof(int));
             aggregate(q, io.adj, lv.S, K, lv.T, K, B, n, K, true, 0.f, j == 0 ? pkp : nullptr, sc.vs, s_split);
             {
                 // both pooled outputs in ONE launch (X' does not need T, but a launch of its own costs more than
                 // waiting for the adjacency pass)
                 GemmDesc d[2] = {
                     {lv.S, lv.Ze, lv.Xn, nullptr, K, li.D, n, K, li.D, li.D, (long)n * K, (long)n * li.D, (long)K * li.D,
-                     true, false, 1.f, 0.f, 0, 0, ksn > 1 ? 1 : 0},
+                     true, false, 1.f, 0.f, 0, 0, 0},
                     {lv.T, lv.S, lv.An, nullptr, K, K, n, K, K, K, (long)n * K, (long)n * K, (long)K * K, true, false, 1.f,
-                     0.f, 0, 0, ksn > 1 ? 1 : 0}};
+                     0.f, 0, 0, 0}};
+                if (ksn > 1) {
+                    d[0].fix_part = fix_part;
+                    d[0].fix_cnt = fix_cnt;
+                    d[1].fix_part = fix_part + (size_t)B * ksn * K * li.D;
+                    d[1].fix_cnt = fix_cnt + gemm_fix_counters(B, K, li.D);
+                }
                 bgemm_group(q, d, 2, B, ksn);
             }
         }

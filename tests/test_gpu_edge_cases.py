@@ -106,8 +106,4 @@ def test_wide_hidden_dims():
 def test_row_kernel_width_classes(H, N, ratio):
     """The row kernels (rownorm backward, bn apply, the softmax plan pair) are compiled per width class with the row
     held in registers; one configuration per class, against the oracle at fp32 tolerance."""
-    # fp32 tolerance: 2e-3 relative, absolute floor 2e-3 of the tensor's largest gradient.  The floor is ten times the
-    # suite's usual one: these bias gradients are sums over up to 1200 rows (x 300 clusters) that nearly cancel, the
-    # oracle and the kernels add them in different orders (atomics, split-K; the K = 300 case moved between runs by
-    # 1.2e-4 on an element 50x below the tensor's maximum), and small elements carry that absolute error.
-    _run(2, N, 9, H, 3, ratio, p=0.05, scale_tol=2e-3)
+    _run(2, N, 9, H, 3, ratio, p=0.05)
