@@ -311,21 +311,30 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, float* lds) {
             *ticket = atomicAdd(a.fix_cnt + (long)b * (((a.M + BM - 1) / BM) * a.tilesN) + tile, 1);
         __syncthreads();
         if (*ticket != a.ksplit - 1) return;               // uniform: somebody else arrives last
+        // range by range (fixed order), every element of the tile in flight per range: ksplit round trips
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int col = n0 + wc * WN + j * 16 + l15;
+            for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k2 = 0; k2 < a.ksplit; ++k2) {
+            f32x4 t[MI][NI];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = min(m0 + wr * WM + i * 16 + l4 * 4 + r, a.M - 1);
-                    const float* src = Pb + (long)row * a.N + min(col, a.N - 1);
-                    float v = 0.f;
-                    for (int k2 = 0; k2 < a.ksplit; ++k2)      // agent-scope loads: past this XCD's caches
-                        v += __hip_atomic_load(src + (long)k2 * pstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    acc[i][j][r] = v;
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int col = min(n0 + wc * WN + j * 16 + l15, a.N - 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = min(m0 + wr * WM + i * 16 + l4 * 4 + r, a.M - 1);
+                        t[i][j][r] = __hip_atomic_load(Pb + (long)k2 * pstride + (long)row * a.N + col, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);      // past this XCD's caches
+                    }
                 }
-            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] += t[i][j];
+        }
     }
     // C/D map of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
