@@ -1,5 +1,5 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01d; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/refresh; mkdir -p $O
 cd $R
 timeout -k 10 200 python3 bench.py > $O/bench_dd.json 2> $O/bench_dd.err
 timeout -k 10 120 python3 bench.py --no-cpu-baseline --linkpred > $O/bench_dd_linkpred.json 2>/dev/null
