@@ -107,3 +107,29 @@ def test_row_kernel_width_classes(H, N, ratio):
     """The row kernels (rownorm backward, bn apply, the softmax plan pair) are compiled per width class with the row
     held in registers; one configuration per class, against the oracle at fp32 tolerance."""
     _run(2, N, 9, H, 3, ratio, p=0.05)
+
+
+def test_forward_is_bit_reproducible_with_split_k_pooling():
+    """A level of 600 nodes at B = 2 pools with split-K contractions over the node index (X' = S^T Z, A' = Tt^T S).
+    Their ranges are combined in a fixed order (partial tiles + tickets, dp_gemm.hip), not with float atomics, so the
+    forward pass is bit-identical from run to run -- with atomics the last bit varied, which could flip a near-tied
+    max-readout winner and reroute a gradient ('Forward determinism')."""
+    B, N, F_, H, Cc = 2, 600, 9, 12, 3
+    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=N // 8, p=0.05, seed=3, n_classes=Cc)
+    model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, 3, H, assign_ratio=0.5, pred_hidden_dims=[50])
+    params = O.init_params({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=3, bias_scale=0.1)
+    model.load_state_dict(params)
+    model = model.cuda()
+    xd, ad = x.cuda(), adj.cuda()
+    first = None
+    for i in range(40):
+        if i % 3 == 1:                                   # perturb allocator state and timing between runs
+            junk = torch.randn((1 + i % 5) * 1024 * 1024, device="cuda")
+            del junk
+        with torch.no_grad():
+            y = model(xd, ad, nn_, assign_x=xd).clone()
+        s = model.assign_tensor.clone()
+        if first is None:
+            first = (y, s)
+        else:
+            assert torch.equal(y, first[0]) and torch.equal(s, first[1]), f"run {i} differs from run 0"
