@@ -802,8 +802,22 @@ __global__ __launch_bounds__(1024) void k_masked_max_fwd(const float* Z, int ldz
     const int nb = num_nodes ? min(num_nodes[b], n) : n;
     float best = -INFINITY;
     int bi = -1;
-    if (f < F) {
-        const float* z = Z + (long)b * n * ldz + f;
+    const float* z = Z + (long)b * n * ldz + min(f, F - 1);
+    if (n <= 16 * 32) {
+        // the thread's (up to) 32 rows are requested in one batch from clamped addresses, compared afterwards: one
+        // memory round trip instead of eight (a compare-and-branch behind each group of four loads)
+        float zv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) zv[u] = z[(long)min(rl + 16 * u, n - 1) * ldz];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int r = rl + 16 * u;
+            if (r < nb && f < F && zv[u] > best) {
+                best = zv[u];
+                bi = r;
+            }
+        }
+    } else if (f < F) {
 #pragma unroll 4
         for (int r = rl; r < nb; r += 16) {
             const float v = z[(long)r * ldz];
