@@ -8,6 +8,19 @@
 
 namespace dp {
 
+#ifdef DP_STAMP
+// diagnostic build only: shader-clock stamps of workgroup 0 ([0,8) forward, [8,16) backward), tools/head_stamps.py
+__device__ unsigned long long g_head_stamps[16];
+#define HEAD_STAMP(i)                                                                                 \
+    do {                                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_head_stamps[i] = __builtin_amdgcn_s_memtime();     \
+    } while (0)
+#else
+#define HEAD_STAMP(i) \
+    do {              \
+    } while (0)
+#endif
+
 constexpr int HEAD_FWD_LDS_FLOATS = 30 * 1024;    // weights + biases + two activation vectors + readout scratch
 constexpr int HEAD_BWD_LDS_FLOATS = 38 * 1024;    // weights + saved activations of the batch + two gradient blocks
 
@@ -35,13 +48,19 @@ __device__ inline void head_stage(float* dst, const float* src, int cnt) {
 // one memory round trip; segments longer than one round finish with stage_rest.
 template <int NT, typename Idx>
 __device__ __forceinline__ void stage_issue(float (&t)[16], const float* src, int cnt, int e0, Idx idx) {
+    // only the slots the segment has (uniform early exit): most segments are a few hundred floats, and sixteen clamped
+    // loads per thread for each of them made the staging instruction-bound (13 k cycles for ~2 300 floats)
 #pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = src[idx(min(e0 + u * NT + (int)threadIdx.x, cnt - 1))];
+    for (int u = 0; u < 16; ++u) {
+        if (e0 + u * NT >= cnt) break;
+        t[u] = src[idx(min(e0 + u * NT + (int)threadIdx.x, cnt - 1))];
+    }
 }
 template <int NT>
 __device__ __forceinline__ void stage_commit(float* dst, const float (&t)[16], int cnt, int e0) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
+        if (e0 + u * NT >= cnt) break;
         const int i = e0 + u * NT + (int)threadIdx.x;
         if (i < cnt) dst[i] = t[u];
     }
@@ -87,6 +106,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* feat = a.hid[0] + (long)b * a.dims[0];
+    HEAD_STAMP(0);
     // (1) readout loads go out first (8 rows per thread in flight, clamped addresses, no branches) ...
     constexpr int RU = 8;
     float zv[RU];
@@ -142,6 +162,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
         for (int k = 4096 + threadIdx.x; k < a.dims[0]; k += 256)
             if (!a.Z || k < a.featoff || k >= a.featoff + a.rw) h0[k] = feat[k];
     }
+    HEAD_STAMP(1);
     if (a.Z) {
         // unmasked max over the nodes of the last level; ties -> lowest row (torch CPU max).  Four row groups x 64
         // columns per pass, combined through LDS.
@@ -189,6 +210,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
         }
     }
     __syncthreads();
+    HEAD_STAMP(2);
     float* cur = h0;
     float* nxt = h1;
     int wo = 0, bo = 0;
@@ -222,6 +244,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
         wo += din * dout;
         bo += dout;
     }
+    HEAD_STAMP(3);
 }
 
 static size_t head_fwd_lds_floats(const HeadArgs& a) {
@@ -264,6 +287,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
     float* F0 = W0 + d1 * HEAD_SLICE;             // [B][ks] slice of the features
     float* g0 = F0 + B * HEAD_SLICE;              // gradient ping / pong [B x mx]
     float* g1 = g0 + (long)B * mx;
+    HEAD_STAMP(8);
     int win[2] = {-1, -1};                        // max-readout winner rows of this thread's first two features
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -313,6 +337,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
         stage_rest<256>(g0, a.d_ypred, cG, ident);
     }
     __syncthreads();
+    HEAD_STAMP(9);
     float* go = g0;
     float* gi = g1;
     int wo = wup, ho = B * hup;
@@ -350,6 +375,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
         __syncthreads();
         float* t = go; go = gi; gi = t;
     }
+    HEAD_STAMP(10);
     // first layer, this workgroup's columns: go is [B x d1]
     float* dW = a.grads + a.h.w_off[0];
     for (int e = threadIdx.x; e < d1 * ks; e += 256) {
@@ -367,6 +393,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
             a.grads[a.h.b_off[0] + j] = s;
         }
     // d(features) of the slice and its max-readout scatter: dZ[b, argmax, f] += dfeat  (dZ zero-initialised by the caller)
+    HEAD_STAMP(11);
     // (a feature belongs to one level; its winner row was asked for at kernel start; dZ is zero on entry -- the caller's
     // contract -- and every (graph, row, feature) is written by one thread, so the scatter is a plain store)
     for (int e = threadIdx.x, it = 0; e < B * ks; e += 256, ++it) {
@@ -383,6 +410,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
             }
         }
     }
+    HEAD_STAMP(12);
 }
 
 static size_t head_bwd_lds_floats(const HeadArgs& a) {
@@ -413,5 +441,11 @@ void head_bwd(Seq& q, const HeadBwdArgs& a) {
     hipLaunchKernelGGL(k_head_bwd, dim3(slices), dim3(256), head_bwd_lds_floats(a.h) * sizeof(float), q.stream, a);
     q.check_launch("head_bwd");
 }
+
+#ifdef DP_STAMP
+extern "C" __attribute__((visibility("default"))) int dp_debug_head_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_head_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
 
 }  // namespace dp
