@@ -17,6 +17,7 @@ DP_MAX_LEVELS = 4
 DP_MAX_PRED = 4
 
 F_ADD_SELF, F_NORMALIZE, F_RELU, F_BN, F_LAST_ONLY = 1, 2, 4, 8, 16
+SAVE_S, SAVE_XPOOL, SAVE_ADJPOOL, SAVE_Z, SAVE_ZASSIGN = 0, 1, 2, 3, 4
 
 
 class StackCfg(C.Structure):
@@ -93,6 +94,7 @@ _PROTOS = {
     "dp_mean_aggregate_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "dp_encoder_save_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "dp_encoder_workspace_bytes": (_Z, [C.POINTER(EncoderCfg)]),
+    "dp_encoder_save_locate": (_I, [C.POINTER(EncoderCfg), _I, _I, C.POINTER(_Z), C.POINTER(_Z)]),
     "dp_encoder_forward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
     "dp_encoder_backward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
     "dp_build_batch": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

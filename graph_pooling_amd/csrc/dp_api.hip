@@ -26,6 +26,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
                      const float* d_assign, float* grads, const void* save);
 size_t encoder_save_bytes(const dp_encoder_cfg& c);
 int encoder_validate(const dp_encoder_cfg* c);
+int encoder_save_locate(const dp_encoder_cfg& c, int level, int field, size_t* offset, size_t* count);
 // dp_set2set.hip
 void set2set_fwd(Seq& q, const float* emb, int lde, const float* w_ih, const float* w_hh, const float* b_ih,
                  const float* b_hh, const float* Wp, const float* bp, float* out, int B, int n, int d, void* save);
@@ -487,6 +488,13 @@ size_t dp_encoder_workspace_bytes(const dp_encoder_cfg* cfg) {
     size_t f = sized([&](Seq& q) { encoder_forward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0); });
     size_t b = sized([&](Seq& q) { encoder_backward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0); });
     return f > b ? f : b;
+}
+int dp_encoder_save_locate(const dp_encoder_cfg* cfg, int level, int field, size_t* offset, size_t* count) {
+    int rc = encoder_validate(cfg);
+    if (rc != DP_OK) return rc;
+    NOTNULL(offset); NOTNULL(count);
+    DP_CHECK_ARG(level >= 0 && level <= cfg->num_pooling, "level=%d out of range [0,%d]", level, cfg->num_pooling);
+    return encoder_save_locate(*cfg, level, field, offset, count);
 }
 int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
                        const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,

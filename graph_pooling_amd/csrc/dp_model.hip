@@ -845,6 +845,33 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
 
 size_t encoder_save_bytes(const dp_encoder_cfg& c) { return layout_save(c, nullptr).total; }
 
+// byte offset / float count of one saved activation of level `level` inside the save buffer (read-back for logging
+// and tests; -1 when the level has no such tensor)
+int encoder_save_locate(const dp_encoder_cfg& c, int level, int field, size_t* offset, size_t* count) {
+    char* const base = reinterpret_cast<char*>(size_t(1) << 20);       // any non-null base: only differences are used
+    SaveLayout sv = layout_save(c, base);
+    const LevelInfo li = level_info(c, level);
+    const LevelSave& lv = sv.lv[level];
+    const size_t B = c.B;
+    const float* p = nullptr;
+    size_t cnt = 0;
+    switch (field) {
+        case DP_SAVE_S: p = lv.S; cnt = B * li.n * li.K; break;
+        case DP_SAVE_XPOOL: p = lv.Xn; cnt = B * li.K * li.D; break;
+        case DP_SAVE_ADJPOOL: p = lv.An; cnt = B * li.K * li.K; break;
+        case DP_SAVE_Z: p = lv.Ze; cnt = B * li.n * li.D; break;
+        case DP_SAVE_ZASSIGN: p = lv.Za; cnt = B * li.n * li.Da; break;
+        default: set_error("dp_encoder_save_locate: unknown field %d", field); return DP_ERR_INVALID_ARG;
+    }
+    if (!p) {
+        set_error("dp_encoder_save_locate: level %d has no field %d", level, field);
+        return DP_ERR_INVALID_ARG;
+    }
+    *offset = (size_t)(reinterpret_cast<const char*>(p) - base);
+    *count = cnt;
+    return DP_OK;
+}
+
 int encoder_validate(const dp_encoder_cfg* c) { return validate(c); }
 
 }  // namespace dp

@@ -141,6 +141,7 @@ class _EncoderFn(torch.autograd.Function):
                                           _lib.ptr(assign), save.data_ptr(), plan.save_bytes,
                                           plan.workspace.data_ptr(), plan.ws_bytes, stream), "dp_encoder_forward")
         ctx.owner, ctx.plan, ctx.save = owner, plan, save
+        owner._last_save = (plan, save)
         ctx.inputs = (x, adj, assign_x, num_nodes, drop)
         ctx.set_materialize_grads(False)
         if assign is None:
@@ -227,6 +228,7 @@ class GcnEncoderGraph(nn.Module):
         self._flat_params = []
         self._plans = {}
         self._last_flat_grad = None
+        self._last_save = None
 
     # -- construction (same names as the reference so state_dict keys match, Appendix D)
     def build_conv_layers(self, input_dim, hidden_dim, embedding_dim, num_layers, add_self,
@@ -436,6 +438,28 @@ class GcnEncoderGraph(nn.Module):
         if x.shape[2] != self.input_dim:
             raise ValueError(f"x has {x.shape[2]} features, the encoder was built for {self.input_dim}")
         return self._run(x, adj, batch_num_nodes)
+
+    def saved_activation(self, level, what):
+        """A view of one activation the LAST forward call kept in its save buffer: what in {'assign', 'xpool',
+        'adjpool', 'embedding', 'assign_embedding'} of pooling level `level` — every level's S_j, X'_j = S_j^T Z_j,
+        A'_j = S_j^T A_j S_j (encoders.py:1273-1279).  The reference keeps only the last S (`assign_tensor`,
+        train.py:218-219 logs it); this reads any level back without a second pass.  The view aliases the buffer:
+        clone it if it must outlive the next forward under no_grad."""
+        field = {"assign": _lib.SAVE_S, "xpool": _lib.SAVE_XPOOL, "adjpool": _lib.SAVE_ADJPOOL,
+                 "embedding": _lib.SAVE_Z, "assign_embedding": _lib.SAVE_ZASSIGN}[what]
+        if getattr(self, "_last_save", None) is None:
+            raise RuntimeError("saved_activation(): no forward pass has run yet")
+        plan, save = self._last_save
+        off, cnt = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(_lib.load().dp_encoder_save_locate(C.byref(plan.cfg), level, field, C.byref(off), C.byref(cnt)),
+                   "dp_encoder_save_locate")
+        flat = save[off.value:off.value + 4 * cnt.value].view(torch.float32)
+        B = plan.cfg.B
+        n = plan.cfg.n_nodes[level]
+        if what in ("embedding", "assign_embedding"):
+            return flat.view(B, n, -1)
+        K = plan.cfg.n_nodes[level + 1]
+        return flat.view(B, n, K) if what == "assign" else flat.view(B, K, -1)
 
     @torch.no_grad()
     def predict(self, x, adj, batch_num_nodes=None, **kwargs):

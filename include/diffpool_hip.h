@@ -232,6 +232,18 @@ size_t dp_sizeof_encoder_cfg(void); /* sizeof(dp_encoder_cfg): lets a binding ch
 size_t dp_encoder_save_bytes(const dp_encoder_cfg* cfg);
 size_t dp_encoder_workspace_bytes(const dp_encoder_cfg* cfg);
 
+/* Where one saved activation of pooling level `level` sits inside the `save` buffer after dp_encoder_forward: the
+ * reference keeps only the LAST level's S as `self.assign_tensor` (encoders.py:1276) for train.py:218-219's logging;
+ * this gives a caller (and the parity tests) every level's S_j [B,n_j,K_j], X'_j [B,K_j,D], A'_j [B,K_j,K_j]
+ * (encoders.py:1278-1279) and the embeddings Z_j [B,n_j,D] / assign-stack outputs [B,n_j,Da_j] without a second pass.
+ * offset is in BYTES from `save`, count in floats.  Returns DP_ERR_INVALID_ARG for a level without that tensor. */
+#define DP_SAVE_S 0
+#define DP_SAVE_XPOOL 1
+#define DP_SAVE_ADJPOOL 2
+#define DP_SAVE_Z 3
+#define DP_SAVE_ZASSIGN 4
+int dp_encoder_save_locate(const dp_encoder_cfg* cfg, int level, int field, size_t* offset, size_t* count);
+
 /* SoftPoolingGcnEncoder.forward (encoders.py:1231-1300), GcnEncoderGraph.forward (:1083-1122,
  * num_pooling = 0) and GcnSet2SetEncoder.forward (:1144-1157, readout = 1).
  * x [B,N,F], adj [B,N,N], assign_x [B,N,Fa] (may alias x), num_nodes int32[B] or NULL.

@@ -7,8 +7,13 @@ the import is patched in-process, with no edits to the reference files
 (SURVEY.md Appendix C):
 
   P1  .cuda() is a no-op (no GPU here; hard-coded .cuda() calls, Appendix B D8)
-  P2  encoders.GraphConv := oracle GraphConv (the DiffPool GraphConv only
-      survives as a comment block, encoders.py:945-974)
+  P2  encoders.GraphConv := the reference's OWN DiffPool GraphConv: the class only survives as a
+      comment block (encoders.py:944-974); its text is read from the reference file at run time,
+      the leading "# " of every line is stripped in memory and the result exec'd in the
+      namespace of the imported `encoders` module (nothing of it is written anywhere).  So every
+      fixture below — including G1, the isolated GraphConv — is produced by the reference's own
+      code for A1, not by the oracle's restatement of it.  (DIFFPOOL_P2=oracle installs the
+      oracle's class instead; both give bit-identical fixtures.)
   P3  while SoftPoolingGcnEncoder.loss runs: the 1-element clamp tensor built by
       torch.Tensor(1) is ones (D5) and `1 - mask.byte()` is a boolean NOT (D6)
 
@@ -42,7 +47,20 @@ import set2set as RS            # noqa: E402
 import aggregators as RA        # noqa: E402
 
 # ---- P2
-R.GraphConv = O.GraphConv
+def reference_graphconv():
+    """The DiffPool GraphConv as the reference wrote it (encoders.py:944-974, a comment block): un-commented in
+    memory and exec'd inside the imported module's namespace (torch / nn / F / init as the reference imported them)."""
+    with open(os.path.join(REF, "encoders.py")) as f:
+        lines = f.read().split("\n")[943:974]
+    assert lines[1].startswith("# class GraphConv(nn.Module):") and lines[-1].strip() == "#         return y", lines
+    text = "\n".join(l[2:] if l.startswith("# ") else l[1:] for l in lines)
+    ns = dict(vars(R))
+    exec(compile(text, "<encoders.py:944-974 un-commented>", "exec"), ns)
+    return ns["GraphConv"]
+
+
+RefGraphConv = reference_graphconv()
+R.GraphConv = O.GraphConv if os.environ.get("DIFFPOOL_P2") == "oracle" else RefGraphConv
 
 
 class _NotMask(torch.Tensor):
@@ -102,6 +120,37 @@ def load_params(model, params):
 
 def pack_params(prefix, params):
     return {f"{prefix}{k}": v for k, v in params.items()}
+
+
+# =========================================================================== G1
+def g1_graphconv():
+    """Isolated GraphConv.forward / backward (encoders.py:962-974) from the reference's own text:
+    add_self x bias, normalize on (as every DiffPool caller builds it, encoders.py:1011-1018) and off,
+    with all-zero input rows (padded nodes) and — bias off — all-zero OUTPUT rows, where F.normalize's
+    subgradient matters."""
+    B, n, fin, fout = 3, 10, 5, 7
+    x, adj, nn_, _ = O.make_batch(B, n, fin, n_min=1, sizes=[10, 4, 1], p=0.35, seed=61, onehot=False)
+    case = 0
+    for add_self in (False, True):
+        for bias in (False, True):
+            for normalize in (True, False):
+                gen = torch.Generator().manual_seed(600 + case)
+                m = RefGraphConv(fin, fout, add_self=add_self, normalize_embedding=normalize, bias=bias)
+                w = (torch.rand(fin, fout, generator=gen) * 2 - 1) * 0.8
+                params = {"weight": w}
+                if bias:
+                    params["bias"] = (torch.rand(fout, generator=gen) * 2 - 1) * 0.3
+                load_params(m, params)
+                xg = x.clone().requires_grad_(True)
+                ag = adj.clone().requires_grad_(True)
+                y = m(xg, ag)
+                g = torch.randn(y.shape, generator=gen)
+                (y * g).sum().backward()
+                grads = {f"grad.{k}": p.grad for k, p in m.named_parameters()}
+                save(f"g1_graphconv_s{int(add_self)}b{int(bias)}n{int(normalize)}", x=x, adj=adj, num_nodes=nn_, y=y,
+                     gy=g, gx=xg.grad, gadj=ag.grad, cfg=np.array([int(add_self), int(bias), int(normalize)]),
+                     **pack_params("param.", params), **grads)
+                case += 1
 
 
 # =========================================================================== G2
@@ -298,6 +347,7 @@ def g10_adam():
 def main():
     random.seed(0)
     np.random.seed(0)
+    g1_graphconv()
     g2_apply_bn()
     g3_gcn_forward()
     g4_g5_softpool()

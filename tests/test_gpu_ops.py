@@ -237,6 +237,46 @@ def test_gcn_layer_fwd_bwd(lib, add_self, bias, normalize, B, n, fin, fout):
         close(db, bo.grad, 1e-3, 1e-4)
 
 
+@pytest.mark.parametrize("name", [f"g1_graphconv_s{s}b{b}n{n}" for s in (0, 1) for b in (0, 1) for n in (1, 0)])
+def test_gcn_layer_against_reference_golden_g1(lib, golden, name):
+    """dp_gcn_layer_fwd/bwd against G1: the reference's own GraphConv text (encoders.py:944-974) run in the build
+    container (oracle/make_golden.py P2) — add_self x bias x normalize, padded zero rows, zero OUTPUT rows."""
+    a, p, g = golden(name)
+    add_self, bias, normalize = [int(v) for v in a["cfg"]]
+    x, adj, W = torch.from_numpy(a["x"]), torch.from_numpy(a["adj"]), p["weight"]
+    B, n, fin = x.shape
+    fout = W.shape[1]
+    flags = (1 if add_self else 0) | (2 if normalize else 0)
+    xd, ad, Wd, dyd = dev(x), dev(adj), dev(W), dev(torch.from_numpy(a["gy"]))
+    bd = dev(p["bias"]) if bias else None
+    y = torch.empty(B, n, fout, device="cuda")
+    invn = torch.empty(B, n, device="cuda")
+    wsb = lib.dp_gcn_layer_workspace_bytes(B, n, fin, fout)
+    ws = ws_of(wsb)
+    _lib.check(lib.dp_gcn_layer_fwd(xd.data_ptr(), fin, ad.data_ptr(), Wd.data_ptr(), _lib.ptr(bd), y.data_ptr(), fout,
+                                    invn.data_ptr(), B, n, fin, fout, flags, ws.data_ptr(), wsb, S()))
+    close(y, torch.from_numpy(a["y"]))
+    dx, dadj = torch.empty_like(xd), torch.empty_like(ad)
+    dW, db = torch.empty_like(Wd), torch.empty(fout, device="cuda")
+    _lib.check(lib.dp_gcn_layer_bwd(xd.data_ptr(), fin, ad.data_ptr(), Wd.data_ptr(), y.data_ptr(), fout,
+                                    invn.data_ptr(), dyd.data_ptr(), fout, dx.data_ptr(), fin, dW.data_ptr(),
+                                    db.data_ptr() if bias else None, dadj.data_ptr(), B, n, fin, fout, flags,
+                                    ws.data_ptr(), wsb, S()))
+    # zero OUTPUT rows (bias off, padded rows): F.normalize's clamp gives d u = d y / 1e-12, so some gradient entries
+    # are ~1e12 next to O(1) ones — huge entries are compared relatively, the rest with the usual atol
+    def mixed(got, ref):
+        got, ref = got.detach().cpu(), ref.detach().cpu()
+        assert torch.isfinite(got).all()
+        big = ref.abs() > 1e6
+        torch.testing.assert_close(got[big], ref[big], rtol=1e-3, atol=0.0)
+        torch.testing.assert_close(got[~big], ref[~big], rtol=1e-3, atol=1e-5)
+    mixed(dx, torch.from_numpy(a["gx"]))
+    mixed(dadj, torch.from_numpy(a["gadj"]))
+    mixed(dW, g["weight"])
+    if bias:
+        mixed(db, g["bias"])
+
+
 def test_gcn_layer_zero_rows_use_the_clamp_branch(lib):
     # rows with ||u|| < 1e-12 (padded rows with zero bias): y = 0 and d u = d y / 1e-12 (F.normalize's clamp_min)
     B, n, f = 1, 8, 4

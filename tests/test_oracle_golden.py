@@ -21,6 +21,27 @@ def req(params):
     return {k: v.clone().requires_grad_(True) for k, v in params.items()}
 
 
+G1_CASES = [f"g1_graphconv_s{s}b{b}n{n}" for s in (0, 1) for b in (0, 1) for n in (1, 0)]
+
+
+@pytest.mark.parametrize("name", G1_CASES)
+def test_g1_graphconv_reference_text(name):
+    """A1 pinned by the reference's own (commented-out) GraphConv text, encoders.py:944-974 — see make_golden.py P2."""
+    a, p, g = load_golden(name)
+    add_self, bias, normalize = [bool(v) for v in a["cfg"]]
+    assert bias == ("bias" in p)
+    x = T(a["x"]).requires_grad_(True)
+    adj = T(a["adj"]).requires_grad_(True)
+    P = req(p)
+    y = O.graph_conv(x, adj, P["weight"], P.get("bias"), add_self, normalize)
+    close(y, a["y"], 0, 0)               # same torch ops in the same order: bit-identical
+    (y * T(a["gy"])).sum().backward()
+    close(x.grad, a["gx"], 1e-6, 1e-7)
+    close(adj.grad, a["gadj"], 1e-6, 1e-7)
+    for k in g:
+        close(P[k].grad, g[k], 1e-6, 1e-7)
+
+
 def test_g2_apply_bn():
     a, _, _ = load_golden("g2_apply_bn")
     x = T(a["x"]).requires_grad_(True)
