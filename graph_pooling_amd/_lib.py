@@ -17,7 +17,7 @@ DP_MAX_LEVELS = 4
 DP_MAX_PRED = 4
 
 F_ADD_SELF, F_NORMALIZE, F_RELU, F_BN, F_LAST_ONLY = 1, 2, 4, 8, 16
-SAVE_S, SAVE_XPOOL, SAVE_ADJPOOL, SAVE_Z, SAVE_ZASSIGN = 0, 1, 2, 3, 4
+SAVE_S, SAVE_XPOOL, SAVE_ADJPOOL, SAVE_Z, SAVE_ZASSIGN, SAVE_ARGMAX = 0, 1, 2, 3, 4, 5
 
 
 class StackCfg(C.Structure):

@@ -41,13 +41,20 @@ __device__ unsigned long long g_agg_stamps[32];   // [0,16) plain-store launches
     } while (0)
 #endif
 
+#ifdef DP_STAMP
+#define AGG_DBG(a) ((a).dbg)
+#else
+#define AGG_DBG(a) 0
+#endif
+
 struct AggArgs {
     const float* A;      // [B, n, n]
     const float* V;      // [B, n, C] (ldv)
     int ldv;
     int n, C;
     int tiles;           // row tiles per graph
-    int dbg;             // ablation switches (DP_AGG_DEBUG): 1 no multiply loop, 2 no panel DMA, 4 no V loads
+    int dbg;             // phase-ablation switches (DP_AGG_DEBUG; DP_STAMP diagnostic build only): 1 no multiply loop,
+                         // 2 no panel DMA.  The product build compiles them out (AGG_DBG == 0).
     // exact-bf16 fast path (binary adjacency): packed op(A) [B, n, pk_ld] bf16, the 3-plane bf16 split of V
     // and the device flag written by k_adj_pack (0 = every entry of A is bf16-exact)
     const unsigned short* pk_A;
@@ -141,7 +148,7 @@ __device__ __forceinline__ void accumulate_fp32(const AggArgs& a, int b, int r0,
         load_b(wave, b0);
         load_b(wave + NW, b1);
         // ---------------- panel -> LDS (everything in flight at once)
-        if (a.dbg & 2) {
+        if (AGG_DBG(a) & 2) {
         } else if (!TRANS) {
             // rows r0..r0+RT-1, columns kbase..kbase+kw: pieces (row i, segment s) of 256 floats
             const int pieces = AGG_RT * segs;
@@ -174,7 +181,7 @@ __device__ __forceinline__ void accumulate_fp32(const AggArgs& a, int b, int r0,
             }
             __syncthreads();
         }
-        const int send = (a.dbg & 1) ? 0 : steps;
+        const int send = (AGG_DBG(a) & 1) ? 0 : steps;
         for (int step = wave; step < send; step += 3 * NW) {
             load_b(step + 2 * NW, b2);
             mma(step, b0);
@@ -830,7 +837,7 @@ static int aggw_ct(int C) {
 // panel kernel; it needs the packed adjacency (n >= 128)
 static bool aggw_usable(const PackedAdj* pk, const unsigned short* vs, int B, int n, int C) {
     if (!pk || !vs || n < 128 || C < 1 || C > AGGW_MAX_C) return false;
-    static const int force = getenv("DP_AGG_WIDE") ? atoi(getenv("DP_AGG_WIDE")) : -1;   // tests: 0 never, 1 always
+    const int force = knobs().agg_wide;   // tests: 0 never, 1 always
     if (force >= 0) return force != 0;
     return C > 128 || (long)B * ((n + 127) / 128) >= 512;
 }
@@ -840,13 +847,10 @@ static void launch_aggw(Seq& q, const AggArgs& a, int B) {
     constexpr int KS = CT <= 8 ? 2 : 1;
     constexpr size_t lds = (size_t)2 * 3 * CT * KS * 1024;
     static_assert(lds <= 160 * 1024, "wide aggregation LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate_wide<CT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static DynLdsOnce attr;
+    if (lds > 64 * 1024)
+        ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_aggregate_wide<CT>), (int)lds, "k_aggregate_wide");
+    if (!q.ok()) return;
     AggArgs aa = a;
     aa.tiles = (a.n + 127) / 128;
     aa.vs_ct = (a.C + 15) / 16;
@@ -856,12 +860,10 @@ template <int CT, int WAVES>
 static void launch_aggw_dma(Seq& q, const AggArgs& a, int B) {
     constexpr size_t lds = ((size_t)2 * 3 * CT * 512 + 3 * WAVES * 1024) * sizeof(unsigned short);
     static_assert(lds <= 160 * 1024, "wide aggregation LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate_wide_dma<CT, WAVES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static DynLdsOnce attr;
+    ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_aggregate_wide_dma<CT, WAVES>), (int)lds,
+                   "k_aggregate_wide_dma");
+    if (!q.ok()) return;
     AggArgs aa = a;
     aa.tiles = (a.n + 32 * WAVES - 1) / (32 * WAVES);
     aa.vs_ct = (a.C + 15) / 16;
@@ -896,7 +898,7 @@ static size_t agg_lds_bytes(bool trans, int n, int CT, int RT, int NW = 4) {
 // panel), so halving the tile count halves the dominant on-chip traffic (DD: 0.424 -> 0.418 ms per step).
 static int agg_row_tile(int B, int n, int C, bool trans) {
     if (agg_lds_bytes(trans, n, agg_ct(C), 32) > 160 * 1024) return 16;   // 32 rows do not fit
-    static const int force = getenv("DP_AGG_RT") ? atoi(getenv("DP_AGG_RT")) : 0;   // tuning knob
+    const int force = knobs().agg_rt;   // tuning knob
     if (force == 16 || force == 32) return force;
     return ((long)((n + 31) / 32) * B >= 256) ? 32 : 16;
 }
@@ -913,17 +915,13 @@ bool aggregate_supported(const float* A, int n, int C, bool trans) {
 template <bool TRANS, int CT, int RT, int NW>
 static void launch_agg_rt(Seq& q, const AggArgs& a, int B) {
     const size_t lds = agg_lds_bytes(TRANS, a.n, CT, RT, NW);
-    static bool attr_done = false;   // per instantiation: allow > 64 KiB of dynamic LDS
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate<TRANS, CT, RT, NW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static DynLdsOnce attr;   // per instantiation: allow > 64 KiB of dynamic LDS
+    ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_aggregate<TRANS, CT, RT, NW>), 160 * 1024, "k_aggregate");
+    if (!q.ok()) return;
     AggArgs aa = a;
     aa.tiles = (a.n + RT - 1) / RT;
     aa.vs_ct = (a.C + 15) / 16;
-    static const int dbg = getenv("DP_AGG_DEBUG") ? atoi(getenv("DP_AGG_DEBUG")) : 0;
-    aa.dbg = dbg;
+    aa.dbg = knobs().agg_debug;     // phase-ablation mask: DP_STAMP diagnostic builds only, 0 in the product
     hipLaunchKernelGGL((k_aggregate<TRANS, CT, RT, NW>), dim3(aa.tiles * B), dim3(NW * 64), lds, q.stream, aa);
 }
 template <bool TRANS, int CT>
@@ -1043,7 +1041,7 @@ void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int
 }
 int adj_pack_ld(int n) { return (n + 7) & ~7; }
 bool adj_pack_supported(int n, int C) {
-    static const bool off = getenv("DP_NO_PACK") != nullptr;      // ablation: fp32 adjacency passes everywhere
+    const bool off = knobs().no_pack;      // ablation: fp32 adjacency passes everywhere
     if (off) return false;
     // worth it only for big levels; the bf16 panel of a 32-row tile must fit LDS beside the reduction area
     return n >= 128 && C >= 1 && C <= AGGW_MAX_C &&

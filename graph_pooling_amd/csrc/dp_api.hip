@@ -17,6 +17,49 @@ void set_error(const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 
+const Knobs& knobs() {
+    static Knobs k;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        auto num = [](const char* name, long dflt) {
+            const char* e = getenv(name);
+            return e ? atol(e) : dflt;
+        };
+        k.agg_wide = (int)num("DP_AGG_WIDE", -1);
+        k.agg_rt = (int)num("DP_AGG_RT", 0);
+#ifdef DP_STAMP
+        k.agg_debug = (int)num("DP_AGG_DEBUG", 0);
+#else
+        k.agg_debug = 0;
+#endif
+        k.no_pack = getenv("DP_NO_PACK") != nullptr;
+        k.gemm_trace = getenv("DP_GEMM_TRACE") != nullptr;
+        k.gemm_target_wgs = num("DP_GEMM_TARGET_WGS", 0);
+        k.node_ksplit = (int)num("DP_NODE_KSPLIT", 0);
+        k.no_head_fusion = getenv("DP_NO_HEAD_FUSION") != nullptr;
+        k.no_level_fusion = getenv("DP_NO_LEVEL_FUSION") != nullptr;
+        k.no_split_gemm = getenv("DP_NO_SPLIT_GEMM") != nullptr;
+    });
+    return k;
+}
+
+void ensure_dyn_lds(Seq& q, DynLdsOnce& st, const void* fn, int bytes, const char* what) {
+    if (q.err || q.dry) return;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && dev >= 0 && dev < 64 &&
+        (st.done.load(std::memory_order_acquire) >> dev & 1ull))
+        return;
+    std::lock_guard<std::mutex> lock(st.m);
+    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(max dynamic LDS = %d): %s", what, bytes, hipGetErrorString(e));
+        q.err = (int)e;
+        return;
+    }
+    if (dev >= 0 && dev < 64) st.done.fetch_or(1ull << dev, std::memory_order_release);
+}
+
 // dp_model.hip
 int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                     const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,

@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 
 #include "../../include/diffpool_hip.h"
 
@@ -111,6 +113,33 @@ struct Seq {
 };
 
 inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+
+// ----------------------------------------------------------------- process-wide read-only state
+// Environment knobs are read ONCE, under std::call_once, on the first library call (dp_api.hip: knobs()); afterwards
+// the table is read-only, so launch sequences on different host threads / streams share no mutable state.  They are
+// tuning and ablation switches for bench runs; none changes results (the one switch that does — the aggregation
+// kernel's phase-ablation mask DP_AGG_DEBUG — exists only in the DP_STAMP diagnostic build).
+struct Knobs {
+    int agg_wide;          // DP_AGG_WIDE: -1 heuristic, 0 never, 1 always take the wide aggregation kernels
+    int agg_rt;            // DP_AGG_RT: 0 heuristic, 16 / 32 row tiles of the panel kernel
+    int agg_debug;         // DP_AGG_DEBUG (DP_STAMP builds only; always 0 in the product library)
+    bool no_pack;          // DP_NO_PACK: fp32 adjacency passes everywhere (ablation)
+    bool gemm_trace;       // DP_GEMM_TRACE: host-side shape log, one line per launch
+    long gemm_target_wgs;  // DP_GEMM_TARGET_WGS: workgroups wanted before GEMM tiles grow (0: default)
+    int node_ksplit;       // DP_NODE_KSPLIT: 0 heuristic, 1..8 forced split-K of the node-index contractions
+    bool no_head_fusion;   // DP_NO_HEAD_FUSION: pred_model on the generic GEMM
+    bool no_level_fusion;  // DP_NO_LEVEL_FUSION: pooled-level GCN stacks one launch per layer
+    bool no_split_gemm;    // DP_NO_SPLIT_GEMM: fp32 MFMA for every GEMM (no split-bf16 products)
+};
+const Knobs& knobs();
+
+// Raising a kernel's dynamic-LDS limit (hipFuncSetAttribute) once per (kernel, device): thread-safe, and the
+// hipError_t goes into the launch sequence instead of being dropped.  One function-local static per kernel.
+struct DynLdsOnce {
+    std::atomic<unsigned long long> done{0};   // bit d: device ordinal d has the attribute
+    std::mutex m;
+};
+void ensure_dyn_lds(Seq& q, DynLdsOnce& st, const void* fn, int bytes, const char* what);
 
 // ------------------------------------------------------------- kernel launchers
 // (dp_gemm.hip)

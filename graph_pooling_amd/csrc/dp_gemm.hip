@@ -484,8 +484,7 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
         if (s.N > maxN) maxN = s.N;
     }
     if (g.count == 0) return;
-    static const bool trace = getenv("DP_GEMM_TRACE") != nullptr;   // host-side shape log, one line per launch
-    if (trace) {
+    if (knobs().gemm_trace) {   // host-side shape log, one line per launch
         fprintf(stderr, "bgemm batch=%d ksplit=%d:", batch, ksplit);
         for (int i = 0; i < g.count; ++i)
             fprintf(stderr, " [%dx%dx%d %c%c%s%s]", g.p[i].M, g.p[i].N, g.p[i].K, g.p[i].tA ? 'T' : 'N',
@@ -493,10 +492,7 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
         fprintf(stderr, "\n");
     }
     // Largest tile that still gives >= TARGET workgroups (256 CUs x 2); smallest tile otherwise.
-    static const long TARGET = [] {
-        const char* e = getenv("DP_GEMM_TARGET_WGS");   // tuning knob: workgroups wanted before tiles grow
-        return e ? atol(e) : 512L;
-    }();
+    const long TARGET = knobs().gemm_target_wgs > 0 ? knobs().gemm_target_wgs : 512L;   // tuning knob
     auto wgs = [&](int bm, int bn) {
         long t = 0;
         for (int i = 0; i < g.count; ++i)

@@ -253,12 +253,10 @@ static size_t head_fwd_lds_floats(const HeadArgs& a) {
 }
 void head_fwd(Seq& q, const HeadArgs& a) {
     if (!q.ok()) return;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  HEAD_FWD_LDS_FLOATS * (int)sizeof(float));
-        attr = true;
-    }
+    static DynLdsOnce attr;
+    ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_head_fwd), HEAD_FWD_LDS_FLOATS * (int)sizeof(float),
+                   "k_head_fwd");
+    if (!q.ok()) return;
     hipLaunchKernelGGL(k_head_fwd, dim3(a.B), dim3(256), head_fwd_lds_floats(a) * sizeof(float), q.stream, a);
     q.check_launch("head_fwd");
 }
@@ -431,12 +429,10 @@ bool head_supported(const HeadArgs& a) {
 
 void head_bwd(Seq& q, const HeadBwdArgs& a) {
     if (!q.ok()) return;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  HEAD_BWD_LDS_FLOATS * (int)sizeof(float));
-        attr = true;
-    }
+    static DynLdsOnce attr;
+    ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_head_bwd), HEAD_BWD_LDS_FLOATS * (int)sizeof(float),
+                   "k_head_bwd");
+    if (!q.ok()) return;
     const int slices = (a.h.dims[0] + HEAD_SLICE - 1) / HEAD_SLICE;
     hipLaunchKernelGGL(k_head_bwd, dim3(slices), dim3(256), head_bwd_lds_floats(a.h) * sizeof(float), q.stream, a);
     q.check_launch("head_bwd");

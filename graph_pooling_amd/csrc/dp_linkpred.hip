@@ -299,19 +299,15 @@ static int lk_kt(int K) {
     return 0;
 }
 
-template <typename F>
-static void lk_set_lds(F* fn, size_t bytes) {
-    // every instantiation is raised once to what it can ever need (static + dynamic LDS must stay within 160 KiB)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
+// every instantiation is raised once per device to what it can ever need (static + dynamic LDS stay within 160 KiB)
 
 template <int KT>
 static void launch_link_fwd(Seq& q, const float* S, int lds_ld, const float* adj, const int* num_nodes, int B, int n,
                             int K, int tiles, float* partial) {
     constexpr size_t bytes = ((size_t)2 * 64 * (KT * 16 + 2) + 4) * sizeof(float);
-    static bool attr = false;
-    if (!attr && bytes > 64 * 1024) lk_set_lds(&k_link_fwd<KT>, bytes);
-    attr = true;
+    static DynLdsOnce attr;
+    if (bytes > 64 * 1024) ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_link_fwd<KT>), (int)bytes, "k_link_fwd");
+    if (!q.ok()) return;
     hipLaunchKernelGGL((k_link_fwd<KT>), dim3(tiles * tiles, B), dim3(256), bytes, q.stream, S, lds_ld, adj, num_nodes,
                        n, K, tiles, partial);
 }
@@ -345,9 +341,10 @@ static void launch_link_bwd(Seq& q, const float* S, int lds_ld, const float* adj
     constexpr int CW = 32 * NJ, KP = KT * 16 + 2;
     constexpr size_t bytes = ((size_t)(64 + CW) * KP + 64 * (CW + 4) + CW * 65) * sizeof(float);
     static_assert(bytes <= 160 * 1024, "link_bwd LDS");
-    static bool attr = false;
-    if (!attr && bytes > 64 * 1024) lk_set_lds(&k_link_bwd<KT, NJ>, bytes);
-    attr = true;
+    static DynLdsOnce attr;
+    if (bytes > 64 * 1024)
+        ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_link_bwd<KT, NJ>), (int)bytes, "k_link_bwd");
+    if (!q.ok()) return;
     hipLaunchKernelGGL((k_link_bwd<KT, NJ>), dim3((n + 63) / 64, B, part ? splits : 1), dim3(256), bytes, q.stream, S,
                        lds_ld, adj, num_nodes, scale, dS, ldds, n, K, accumulate, part, split_tiles);
 }

@@ -209,7 +209,7 @@ RowGroups groups_of(const LevelInfo& li, int l) {
 // big graphs need it to fill the chip, large batches do not.
 int node_ksplit(const dp_encoder_cfg& c) {
     if (c.B >= 64) return 1;
-    static const int force = getenv("DP_NODE_KSPLIT") ? atoi(getenv("DP_NODE_KSPLIT")) : 0;   // tuning knob
+    const int force = knobs().node_ksplit;   // tuning knob
     if (force >= 1 && force <= 8) return force;
     int ks = (c.N + 127) / 128;
     return ks < 1 ? 1 : (ks > 8 ? 8 : ks);
@@ -527,8 +527,7 @@ HeadArgs head_args(const dp_encoder_cfg& c, const SaveLayout& sv, const float* p
 }
 bool head_usable(const dp_encoder_cfg& c) {
     if (c.readout != 0) return false;
-    static const bool off = getenv("DP_NO_HEAD_FUSION") != nullptr;
-    if (off) return false;
+    if (knobs().no_head_fusion) return false;
     HeadArgs h{};
     h.n_pred = c.n_pred;
     h.B = c.B;
@@ -853,9 +852,10 @@ int encoder_save_locate(const dp_encoder_cfg& c, int level, int field, size_t* o
     const LevelInfo li = level_info(c, level);
     const LevelSave& lv = sv.lv[level];
     const size_t B = c.B;
-    const float* p = nullptr;
+    const void* p = nullptr;
     size_t cnt = 0;
     switch (field) {
+        case DP_SAVE_ARGMAX: p = lv.argmax; cnt = B * readout_width(c, li); break;
         case DP_SAVE_S: p = lv.S; cnt = B * li.n * li.K; break;
         case DP_SAVE_XPOOL: p = lv.Xn; cnt = B * li.K * li.D; break;
         case DP_SAVE_ADJPOOL: p = lv.An; cnt = B * li.K * li.K; break;
@@ -867,7 +867,7 @@ int encoder_save_locate(const dp_encoder_cfg& c, int level, int field, size_t* o
         set_error("dp_encoder_save_locate: level %d has no field %d", level, field);
         return DP_ERR_INVALID_ARG;
     }
-    *offset = (size_t)(reinterpret_cast<const char*>(p) - base);
+    *offset = (size_t)(static_cast<const char*>(p) - base);
     *count = cnt;
     return DP_OK;
 }

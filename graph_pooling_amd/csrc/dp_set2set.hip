@@ -393,14 +393,9 @@ void set2set_fwd(Seq& q, const float* emb, int lde, const float* w_ih, const flo
     a.w_in_lds = s2s_w_fits(n, d) ? 1 : 0;
     a.emb_in_lds = s2s_emb_fits(n, d) ? 1 : 0;
     const size_t ldsb = s2s_dyn_lds(n, d, a.w_in_lds, a.emb_in_lds);
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_set2set_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_set2set_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-        attr = true;
-    }
+    static DynLdsOnce attr;
+    ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_set2set_fwd), 160 * 1024, "k_set2set_fwd");
+    if (!q.ok()) return;
     hipLaunchKernelGGL(k_set2set_fwd, dim3(B), dim3(256), ldsb, q.stream, a);
     q.check_launch("set2set_fwd");
 }
@@ -424,12 +419,9 @@ void set2set_bwd(Seq& q, const float* emb, int lde, const float* w_ih, const flo
     a.n = n; a.d = d; a.GS = L.GS;
     a.w_in_lds = s2s_w_fits(n, d) ? 1 : 0;
     a.emb_in_lds = s2s_emb_fits(n, d) ? 1 : 0;
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_set2set_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-        attr = true;
-    }
+    static DynLdsOnce attr;
+    ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_set2set_bwd), 160 * 1024, "k_set2set_bwd");
+    if (!q.ok()) return;
     hipLaunchKernelGGL(k_set2set_bwd, dim3(B), dim3(256), s2s_dyn_lds(n, d, a.w_in_lds, a.emb_in_lds), q.stream, a);
     q.check_launch("set2set_bwd");
     const float* QP = sv + L.qp;
@@ -448,7 +440,8 @@ void set2set_bwd(Seq& q, const float* emb, int lde, const float* w_ih, const flo
         bgemm_group(q, g, 2, 1);
     }
     colsum_batched(q, DG, 4 * d, 0, B * T, 4 * d, db_ih, 0, 1);
-    q.copy(db_hh, db_ih, (size_t)4 * d * sizeof(float));
+    // b_ih and b_hh enter the gates as a sum: the same gradient, written by the same kernel (no memcpy node on this path)
+    colsum_batched(q, DG, 4 * d, 0, B * T, 4 * d, db_hh, 0, 1);
     // demb[b] = A_b^T DR_b + DE_b^T H_b
     bgemm(q, Aw, DR, demb, nullptr, B, n, d, T, n, d, ldde, (long)T * n, (long)T * d, (long)n * ldde, true, false, 1.f,
           0.f, 0);

@@ -425,15 +425,10 @@ bool small_level_supported(int B, int n, int din, int dout) {
     return (f > bw ? f : bw) * sizeof(float) <= 150 * 1024;
 }
 
-static void small_attr() {
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_gcn_fwd),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_gcn_bwd),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        done = true;
-    }
+static void small_attr(Seq& q) {
+    static DynLdsOnce fwd, bwd;
+    ensure_dyn_lds(q, fwd, reinterpret_cast<const void*>(&k_small_gcn_fwd), 160 * 1024, "k_small_gcn_fwd");
+    ensure_dyn_lds(q, bwd, reinterpret_cast<const void*>(&k_small_gcn_bwd), 160 * 1024, "k_small_gcn_bwd");
 }
 
 void small_gcn_fwd(Seq& q, const float* adj, const float* x0, int ldx0, const float* yprev, int ldyp,
@@ -441,7 +436,8 @@ void small_gcn_fwd(Seq& q, const float* adj, const float* x0, int ldx0, const fl
                    float* y, int ldy, float* invn, float* part, int B, int n, int din, int dout, int add_self,
                    int stats) {
     if (!q.ok()) return;
-    small_attr();
+    small_attr(q);
+    if (!q.ok()) return;
     SmallFwdArgs a{adj, x0, ldx0, yprev, ldyp, part_prev, stats_prev, xout, ldxo, W, bias, y, ldy, invn, part,
                    B, n, din, dout, add_self, stats, sm_div(din)};
     hipLaunchKernelGGL(k_small_gcn_fwd, dim3(B), dim3(1024), small_lds_floats_fwd(B, n, din, dout) * sizeof(float),
@@ -455,7 +451,8 @@ void small_gcn_bwd(Seq& q, const float* adj, const float* xin, int ldxin, const 
                    float* db, long slab_stride, int B, int n, int din, int dout, int add_self, int has_bn,
                    int has_relu) {
     if (!q.ok()) return;
-    small_attr();
+    small_attr(q);
+    if (!q.ok()) return;
     SmallBwdArgs a{adj, xin, ldxin, W, y, ldy, xhat, ldxh, invn, stats, part2, dx, lddx, dxin, lddxin, part2_prev,
                    dadj, dW, db, slab_stride, B, n, din, dout, add_self, has_bn, has_relu, sm_div(din), sm_div(dout)};
     hipLaunchKernelGGL(k_small_gcn_bwd, dim3(B), dim3(1024), small_lds_floats_bwd(B, n, din, dout) * sizeof(float),

@@ -441,20 +441,24 @@ class GcnEncoderGraph(nn.Module):
 
     def saved_activation(self, level, what):
         """A view of one activation the LAST forward call kept in its save buffer: what in {'assign', 'xpool',
-        'adjpool', 'embedding', 'assign_embedding'} of pooling level `level` — every level's S_j, X'_j = S_j^T Z_j,
+        'adjpool', 'embedding', 'assign_embedding', 'readout_argmax'} of pooling level `level` — every level's S_j, X'_j = S_j^T Z_j,
         A'_j = S_j^T A_j S_j (encoders.py:1273-1279).  The reference keeps only the last S (`assign_tensor`,
         train.py:218-219 logs it); this reads any level back without a second pass.  The view aliases the buffer:
         clone it if it must outlive the next forward under no_grad."""
         field = {"assign": _lib.SAVE_S, "xpool": _lib.SAVE_XPOOL, "adjpool": _lib.SAVE_ADJPOOL,
-                 "embedding": _lib.SAVE_Z, "assign_embedding": _lib.SAVE_ZASSIGN}[what]
+                 "embedding": _lib.SAVE_Z, "assign_embedding": _lib.SAVE_ZASSIGN,
+                 "readout_argmax": _lib.SAVE_ARGMAX}[what]
         if getattr(self, "_last_save", None) is None:
             raise RuntimeError("saved_activation(): no forward pass has run yet")
         plan, save = self._last_save
         off, cnt = C.c_size_t(0), C.c_size_t(0)
         _lib.check(_lib.load().dp_encoder_save_locate(C.byref(plan.cfg), level, field, C.byref(off), C.byref(cnt)),
                    "dp_encoder_save_locate")
-        flat = save[off.value:off.value + 4 * cnt.value].view(torch.float32)
+        raw = save[off.value:off.value + 4 * cnt.value]
         B = plan.cfg.B
+        if what == "readout_argmax":       # int32 [B, readout width]; -1 where a masked (zero) row holds the maximum
+            return raw.view(torch.int32).view(B, -1)
+        flat = raw.view(torch.float32)
         n = plan.cfg.n_nodes[level]
         if what in ("embedding", "assign_embedding"):
             return flat.view(B, n, -1)

@@ -236,12 +236,13 @@ size_t dp_encoder_workspace_bytes(const dp_encoder_cfg* cfg);
  * reference keeps only the LAST level's S as `self.assign_tensor` (encoders.py:1276) for train.py:218-219's logging;
  * this gives a caller (and the parity tests) every level's S_j [B,n_j,K_j], X'_j [B,K_j,D], A'_j [B,K_j,K_j]
  * (encoders.py:1278-1279) and the embeddings Z_j [B,n_j,D] / assign-stack outputs [B,n_j,Da_j] without a second pass.
- * offset is in BYTES from `save`, count in floats.  Returns DP_ERR_INVALID_ARG for a level without that tensor. */
+ * offset is in BYTES from `save`, count in 4-byte elements.  Returns DP_ERR_INVALID_ARG for a level without that tensor. */
 #define DP_SAVE_S 0
 #define DP_SAVE_XPOOL 1
 #define DP_SAVE_ADJPOOL 2
 #define DP_SAVE_Z 3
 #define DP_SAVE_ZASSIGN 4
+#define DP_SAVE_ARGMAX 5   /* int32 [B, readout width]: winning row of the max readout (-1: a masked zero row) */
 int dp_encoder_save_locate(const dp_encoder_cfg* cfg, int level, int field, size_t* offset, size_t* count);
 
 /* SoftPoolingGcnEncoder.forward (encoders.py:1231-1300), GcnEncoderGraph.forward (:1083-1122,

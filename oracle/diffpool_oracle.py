@@ -157,7 +157,8 @@ def level_keys(level: int, num_pooling: int, n_layers: int):
 def softpool_forward(params: Dict[str, Tensor], x: Tensor, adj: Tensor, num_nodes,
                      assign_x: Optional[Tensor] = None, *, num_layers: int = 3,
                      num_pooling: int = 1, n_pred_hidden: int = 1, bn: bool = True,
-                     want_intermediates: bool = False, drop: Optional[Dict[str, Tensor]] = None):
+                     want_intermediates: bool = False, drop: Optional[Dict[str, Tensor]] = None,
+                     winners: Optional[Sequence[Tensor]] = None):
     """SoftPoolingGcnEncoder.forward, encoders.py:1231-1300, with the index fixes of
     SURVEY.md Appendix B (D3: per-level assign_pred; D4: level>=1 assign input = X').
 
@@ -165,14 +166,26 @@ def softpool_forward(params: Dict[str, Tensor], x: Tensor, adj: Tensor, num_node
     flag; the level-0 embedding GCN always batch-norms (encoders.py:1172-1173 does
     not forward `bn`, so self.bn stays True — and self.bn is what gcn_forward reads
     for every stack, encoders.py:1063).  Hence bn here is effectively always True
-    for SoftPoolingGcnEncoder; the argument exists for the base encoders."""
+    for SoftPoolingGcnEncoder; the argument exists for the base encoders.
+
+    `winners` (tests only): per level an int tensor [B, D] of row indices that REPLACE the arg-max of the max
+    readout (-1: the output is the constant 0 of a masked row).  torch.max routes the gradient to whichever row wins;
+    two rows tied to within rounding can swap between an fp32 and an fp64 run, which changes whole gradient entries
+    although both are valid.  Forcing the decisions of the run under test makes an fp64 run of this function the exact
+    gradient of THAT forward pass."""
+    def readout(z, level):
+        if winners is None:
+            return z.max(dim=1)[0]
+        idx = winners[level].to(torch.int64)
+        got = z.gather(1, idx.clamp_min(0).unsqueeze(1)).squeeze(1)
+        return torch.where(idx >= 0, got, torch.zeros((), dtype=z.dtype))
     B, N, _ = x.shape
     x_a = x if assign_x is None else assign_x
     mask = node_mask(N, num_nodes, x.dtype) if num_nodes is not None else None
     inter = {}
     emb0 = _stack_keys("conv_first", "conv_block", "conv_last", num_layers)
     z = gcn_stack(x, adj, params, emb0, mask, bn, drop=drop)            # :1254
-    outs = [z.max(dim=1)[0]]                                            # :1257
+    outs = [readout(z, 0)]                                              # :1257
     s0 = None
     for i in range(num_pooling):                                        # :1263
         emb_k, asg_k, pred_k = level_keys(i, num_pooling, num_layers)
@@ -192,7 +205,7 @@ def softpool_forward(params: Dict[str, Tensor], x: Tensor, adj: Tensor, num_node
             inter[f"xpool_{i}"] = xp
             inter[f"adjpool_{i}"] = adj
         z = gcn_stack(xp, adj, params, emb_k, None, bn, drop=drop)      # :1282-1284
-        outs.append(z.max(dim=1)[0])                                    # :1287
+        outs.append(readout(z, i + 1))                                  # :1287
         inter["assign_last"] = s
     feat = torch.cat(outs, dim=1)                                       # :1295-1296
     ypred = mlp_head(feat, params, "pred_model", n_pred_hidden)         # :1299

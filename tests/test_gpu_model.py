@@ -3,8 +3,8 @@ reference's own classes produced (tests/golden, oracle/make_golden.py) and (b) t
 seeded synthetic batches up to BASELINE.json's DD shape.  The modules call libdiffpool_hip.so through
 the C ABI (dp_encoder_forward/backward, dp_loss_forward/backward).
 
-Tolerances (fp32 kernels, reduction-order differences only):
-  ypred / loss / assign: rtol 1e-4, atol 1e-5;   parameter gradients: rtol 2e-3, atol 2e-5.
+Tolerances (fp32 kernels, reduction-order differences only) and the handling of max-readout ties:
+tests/parity.py.
 """
 import numpy as np
 import pytest
@@ -13,27 +13,10 @@ import torch
 from graph_pooling_amd.encoders import GcnEncoderGraph, GcnSet2SetEncoder, SoftPoolingGcnEncoder
 from graph_pooling_amd.set2set import Set2Set
 from oracle import diffpool_oracle as O
+from tests.parity import close, grads_close, gpu_winners
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
-
-
-def close(a, b, rtol=1e-4, atol=1e-5):
-    a = a.detach().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(a)
-    b = b.detach().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(b)
-    assert torch.isfinite(a).all() and torch.isfinite(b).all(), 'non-finite values in a parity check'
-    torch.testing.assert_close(a.float(), b.float(), rtol=rtol, atol=atol)
-
-
-def grads_close(model, ref_grads, rtol=2e-3, atol=2e-5):
-    named = dict(model.named_parameters())
-    assert set(named) == set(ref_grads), set(named) ^ set(ref_grads)
-    for k, p in named.items():
-        assert p.grad is not None, k
-        g = ref_grads[k]
-        # scale atol with the gradient's magnitude so tiny-gradient tensors are still checked relatively
-        scale = float(g.abs().max())
-        close(p.grad, g, rtol=rtol, atol=max(atol, 2e-4 * scale))
 
 
 @pytest.mark.parametrize("name", ["g4_softpool_n16_f3", "g5_softpool_n16_f3_link", "g4_softpool_n100_f89",
@@ -57,6 +40,7 @@ def test_softpool_against_reference_golden(name, golden):
     model = model.cuda()
     xd, ad = x.cuda(), adj.cuda()
     ypred = model(xd, ad, a["num_nodes"], assign_x=xd)
+    win = gpu_winners(model, 2)
     close(ypred, a["ypred"])
     close(model.assign_tensor, a["assign"], 1e-4, 1e-6)
     label = T(a["label"]).cuda()
@@ -65,7 +49,19 @@ def test_softpool_against_reference_golden(name, golden):
     if linkpred:
         close(model.link_loss, a["link_loss"], 1e-5, 1e-6)
     loss.backward()
-    grads_close(model, grads)
+    try:
+        grads_close(model, grads)
+    except AssertionError:
+        # A max-readout tie resolved differently from the reference's own run (tests/parity.py): legitimate only if
+        # (a) the oracle with ITS OWN arg-max reproduces the reference's gradients (the fixture pins the oracle) and
+        # (b) the HIP gradients equal the oracle's with the HIP winners forced, and (c) the winners really differ.
+        _, inter_f, _, g_free = _oracle_run(params, x, adj, a["num_nodes"], T(a["label"]), linkpred)
+        for k, g in grads.items():
+            close(g_free[k], g, 1e-3, max(1e-7, 2e-5 * float(g.abs().max())))
+        _, inter_w, _, g_forced = _oracle_run(params, x, adj, a["num_nodes"], T(a["label"]), linkpred, winners=win)
+        close(inter_w["readout"], inter_f["readout"], 1e-5, 2e-6)
+        grads_close(model, g_forced)
+        assert any(float((g_forced[k] - g_free[k]).abs().max()) > 0 for k in grads), "no tie flip explains the mismatch"
 
 
 @pytest.mark.parametrize("tag", ["concat", "addself", "nobn"])
@@ -89,9 +85,9 @@ def test_base_encoder_against_reference_golden(tag, golden):
     grads_close(model, grads)
 
 
-def _oracle_run(params, x, adj, nn_, label, linkpred, num_pooling=1):
+def _oracle_run(params, x, adj, nn_, label, linkpred, num_pooling=1, winners=None):
     P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    yo, inter = O.softpool_forward(P, x, adj, nn_, x, num_pooling=num_pooling)
+    yo, inter = O.softpool_forward(P, x, adj, nn_, x, num_pooling=num_pooling, winners=winners)
     lo, link = O.softpool_loss(yo, label, inter["assign_0"], adj, nn_, linkpred)
     lo.backward()
     return yo, inter, lo, {k: v.grad for k, v in P.items()}
@@ -114,9 +110,12 @@ def test_softpool_against_oracle_synthetic(B, N, F_, H, Cc, ratio, p, linkpred, 
     model = model.cuda()
     xd, ad = x.cuda(), adj.cuda()
     ypred = model(xd, ad, nn_, assign_x=xd)
+    win = gpu_winners(model, 2)
     loss = model.loss(ypred, label.cuda(), ad, nn_) if linkpred else model.loss(ypred, label.cuda())
     loss.backward()
-    yo, inter, lo, go = _oracle_run(params, x, adj, nn_, label, linkpred)
+    yfree, _ = O.softpool_forward(params, x, adj, nn_, x)
+    close(ypred, yfree)                                   # forward against the oracle's own arg-max
+    yo, inter, lo, go = _oracle_run(params, x, adj, nn_, label, linkpred, winners=win)
     close(ypred, yo)
     close(model.assign_tensor, inter["assign_0"], 1e-4, 1e-6)
     close(loss, lo, 1e-4, 1e-6)
@@ -132,9 +131,11 @@ def test_unmasked_batch_and_full_graphs():
     model.load_state_dict(params)
     model = model.cuda()
     ypred = model(x.cuda(), adj.cuda(), None, assign_x=x.cuda())
+    win = gpu_winners(model, 2)
     loss = model.loss(ypred, label.cuda(), adj.cuda(), None)
     loss.backward()
-    yo, inter, lo, go = _oracle_run(params, x, adj, None, label, True)
+    close(ypred, O.softpool_forward(params, x, adj, None, x)[0])
+    yo, inter, lo, go = _oracle_run(params, x, adj, None, label, True, winners=win)
     close(ypred, yo)
     close(loss, lo, 1e-4, 1e-6)
     grads_close(model, go)
@@ -154,9 +155,11 @@ def test_multi_pool_against_oracle_PARITY_UNPINNED():
     model.load_state_dict(params)
     model = model.cuda()
     ypred = model(x.cuda(), adj.cuda(), nn_, assign_x=x.cuda())
+    win = gpu_winners(model, 3)
     loss = model.loss(ypred, label.cuda(), adj.cuda(), nn_)
     loss.backward()
-    yo, inter, lo, go = _oracle_run(params, x, adj, nn_, label, True, num_pooling=2)
+    close(ypred, O.softpool_forward(params, x, adj, nn_, x, num_pooling=2)[0])
+    yo, inter, lo, go = _oracle_run(params, x, adj, nn_, label, True, num_pooling=2, winners=win)
     close(ypred, yo)
     close(loss, lo, 1e-4, 1e-6)
     grads_close(model, go)
@@ -177,10 +180,12 @@ def _multi_level_case(B, N, F_, H, Cc, ratio, P, linkpred, *, p_edge, n_min, one
     ypred = model(xd, ad, nn_, assign_x=xd)
     loss = model.loss(ypred, label.cuda(), ad, nn_) if linkpred else model.loss(ypred, label.cuda())
     lv = [{w: model.saved_activation(j, w).clone() for w in ("assign", "xpool", "adjpool")} for j in range(P)]
+    win = gpu_winners(model, P + 1)
     loss.backward()
 
+    close(ypred, O.softpool_forward(params, x, adj, nn_, x, num_pooling=P)[0])
     Pm = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    yo, inter = O.softpool_forward(Pm, x, adj, nn_, x, num_pooling=P, want_intermediates=True)
+    yo, inter = O.softpool_forward(Pm, x, adj, nn_, x, num_pooling=P, want_intermediates=True, winners=win)
     lo, _ = O.softpool_loss(yo, label, inter["assign_0"], adj, nn_, linkpred)
     lo.backward()
     for j in range(P):
@@ -255,42 +260,52 @@ def test_er_full_size_properties():
             assert torch.equal(acts[j]["assign"], a0[j]["assign"]) and torch.equal(acts[j]["adjpool"], a0[j]["adjpool"])
 
 
+@pytest.mark.parametrize("seed", [1, 2, 5, 7])
 @pytest.mark.parametrize("tag,B,N,F_,H,Cc,ratio,p,linkpred", [
     ("S-DD", 20, 500, 89, 20, 2, 0.1, 0.02, False),
     ("S-ENZ+link", 20, 100, 3, 20, 6, 0.1, 0.10, True),
 ])
-def test_gradients_no_worse_than_fp32_oracle_vs_fp64(tag, B, N, F_, H, Cc, ratio, p, linkpred):
-    """fp64-anchored gradient check (replaces a loose relative tolerance): the fp32 torch-CPU oracle is itself only an
-    approximation of the exact gradient, so the HIP path is held to the oracle's own distance from an fp64 run of the
-    same restatement:  max|g_gpu - g64| <= 4 * max|g_oracle32 - g64| + 1e-7 * max|g64|  for every parameter tensor."""
-    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=max(1, N // 10), p=p, seed=1, n_classes=Cc)
+def test_gradients_no_worse_than_fp32_oracle_vs_fp64(tag, B, N, F_, H, Cc, ratio, p, linkpred, seed):
+    """fp64-anchored gradient check (instead of a loose relative tolerance): the fp32 torch-CPU oracle is itself only
+    an approximation of the exact gradient, so the HIP path is held to the oracle's own distance from an fp64 run of the
+    same restatement:  max|g_gpu - g64| <= 4 * max|g_oracle32 - g64| + 1e-7 * max|g64|  for EVERY parameter tensor.
+
+    One thing has to be equal on both sides first: the discrete decisions.  torch.max routes the readout gradient to
+    the winning row, and at a pooled level rows tie to ~1e-8 (soft assignments are nearly uniform at init), so the
+    winner of such a tie differs between fp32 and fp64 runs — in the oracle too (tools/grad_anchor_probe.py: 0-5 such
+    flips per batch, each moving whole gradient entries by ~1e-3 relative, on the HIP path and the fp32 oracle alike).
+    So the winners the HIP forward recorded are (1) checked to be legitimate — the value at the recorded row is
+    within rounding of the fp64 maximum — and (2) forced into the fp32 and fp64 oracle runs."""
+    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=max(1, N // 10), p=p, seed=seed, n_classes=Cc)
     model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, 3, H, assign_ratio=ratio, linkpred=linkpred)
-    params = O.init_params({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0, bias_scale=0.1)
+    params = O.init_params({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=seed - 1, bias_scale=0.1)
     model.load_state_dict(params)
     model = model.cuda()
     xd, ad = x.cuda(), adj.cuda()
     ypred = model(xd, ad, nn_, assign_x=xd)
+    winners = gpu_winners(model, 2)
     loss = model.loss(ypred, label.cuda(), ad, nn_) if linkpred else model.loss(ypred, label.cuda())
     loss.backward()
 
-    def oracle(dtype):
+    def oracle(dtype, win):
         Pm = {k: v.clone().to(dtype).requires_grad_(True) for k, v in params.items()}
-        yo, inter = O.softpool_forward(Pm, x.to(dtype), adj.to(dtype), nn_, x.to(dtype))
+        yo, inter = O.softpool_forward(Pm, x.to(dtype), adj.to(dtype), nn_, x.to(dtype), winners=win)
         lo, _ = O.softpool_loss(yo, label, inter["assign_0"], adj.to(dtype), nn_, linkpred)
         lo.backward()
-        return float(lo), {k: v.grad.double() for k, v in Pm.items()}
-    l32, g32 = oracle(torch.float32)
-    l64, g64 = oracle(torch.float64)
+        return float(lo), inter["readout"].detach().double(), {k: v.grad.double() for k, v in Pm.items()}
+    _, feat_free, _ = oracle(torch.float64, None)           # fp64 with its own arg-max
+    l32, _, g32 = oracle(torch.float32, winners)
+    l64, feat_forced, g64 = oracle(torch.float64, winners)
+    # (1) every recorded winner holds the maximum up to rounding
+    assert float((feat_forced - feat_free).abs().max()) <= 2e-6 * max(1.0, float(feat_free.abs().max()))
     assert abs(float(loss) - l64) <= 4 * abs(l32 - l64) + 1e-6 * abs(l64)
-    worst = []
     for k, pm in model.named_parameters():
         gg = pm.grad.detach().cpu().double()
         assert torch.isfinite(gg).all(), k
         e_gpu = float((gg - g64[k]).abs().max())
         e_o32 = float((g32[k] - g64[k]).abs().max())
         bound = 4 * e_o32 + 1e-7 * float(g64[k].abs().max())
-        worst.append((e_gpu / max(bound, 1e-300), k, e_gpu, e_o32))
-        assert e_gpu <= bound, f"{tag} {k}: |gpu-fp64| {e_gpu:.3e} > 4*|oracle32-fp64| {e_o32:.3e} + 1e-7*scale"
+        assert e_gpu <= bound, f"{tag} seed {seed} {k}: |gpu-fp64| {e_gpu:.3e} > 4*|oracle32-fp64| {e_o32:.3e} + 1e-7*scale"
 
 
 def test_adam_two_steps_golden(golden):
