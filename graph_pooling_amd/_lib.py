@@ -17,6 +17,7 @@ DP_MAX_LEVELS = 4
 DP_MAX_PRED = 4
 
 F_ADD_SELF, F_NORMALIZE, F_RELU, F_BN, F_LAST_ONLY = 1, 2, 4, 8, 16
+MODE_EVAL, MODE_TRAIN = 0, 1
 SAVE_S, SAVE_XPOOL, SAVE_ADJPOOL, SAVE_Z, SAVE_ZASSIGN, SAVE_ARGMAX = 0, 1, 2, 3, 4, 5
 
 
@@ -95,13 +96,13 @@ _PROTOS = {
     "dp_encoder_save_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "dp_encoder_workspace_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "dp_encoder_save_locate": (_I, [C.POINTER(EncoderCfg), _I, _I, C.POINTER(_Z), C.POINTER(_Z)]),
-    "dp_encoder_forward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
-    "dp_encoder_backward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
+    "dp_encoder_forward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
+    "dp_encoder_backward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
     "dp_build_batch": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dp_clip_adam_workspace_bytes": (_Z, []),
     "dp_clip_adam_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P, _P, _Z, _P]),
     "dp_loss_workspace_bytes": (_Z, [_I, _I, _I, _I]),
-    "dp_loss_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "dp_loss_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "dp_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
 }
 

@@ -957,9 +957,19 @@ static void dispatch_ct(Seq& q, const AggArgs& a, int B) {
 // was 16 dependent round trips per thread: 11.9 us for the DD batch.)  n % 4 == 0, ld % 8 == 0.
 typedef float agg_f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned short agg_u16x4 __attribute__((ext_vector_type(4)));
+// side job of both pack kernels: the launch's workgroups clear `zn16` 16-byte words at zp between them
+__device__ inline void pack_side_zero(uint4* zp, long zn16) {
+    if (!zp) return;
+    const long nwg = (long)gridDim.x * gridDim.y * gridDim.z;
+    const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const long per = (zn16 + nwg - 1) / nwg;
+    const long end = min(zn16, (wg + 1) * per);
+    for (long i = wg * per + threadIdx.x; i < end; i += 256) zp[i] = make_uint4(0, 0, 0, 0);
+}
 __global__ __launch_bounds__(256) void k_adj_pack(const float* A, unsigned short* P, unsigned short* Pt, int* flag,
-                                                  int n, int ld) {
+                                                  int n, int ld, uint4* zp, long zn16) {
     __shared__ __attribute__((aligned(8))) unsigned short tile[64][68];
+    pack_side_zero(zp, zn16);
     const int b = blockIdx.z;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const float* Ab = A + (long)b * n * n;
@@ -1002,8 +1012,9 @@ __global__ __launch_bounds__(256) void k_adj_pack(const float* A, unsigned short
 
 // any n (the public entry point takes any): one element per thread and pass
 __global__ __launch_bounds__(256) void k_adj_pack_any(const float* A, unsigned short* P, unsigned short* Pt, int* flag,
-                                                      int n, int ld) {
+                                                      int n, int ld, uint4* zp, long zn16) {
     __shared__ unsigned short tile[64][66];
+    pack_side_zero(zp, zn16);
     const int b = blockIdx.z;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const float* Ab = A + (long)b * n * n;
@@ -1028,15 +1039,24 @@ __global__ __launch_bounds__(256) void k_adj_pack_any(const float* A, unsigned s
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
-void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int* flag, int B, int n, int ld) {
+void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int* flag, int B, int n, int ld,
+              bool flag_zeroed, void* zero_p, size_t zero_bytes) {
     if (!q.ok()) return;
-    zero_fill(q, flag, 256);      // (a kernel: captured memset nodes misbehave on replay, see zero_fill)
+    if (!flag_zeroed) zero_fill(q, flag, 256);   // (a kernel: captured memset nodes misbehave on replay, see zero_fill)
     const int t = (ld + 63) / 64;
-    if (B <= 0 || n <= 0) return;
+    if (B <= 0 || n <= 0 || (zero_p && ((reinterpret_cast<uintptr_t>(zero_p) | zero_bytes) & 15))) {
+        if (zero_p) zero_fill(q, zero_p, zero_bytes);
+        zero_p = nullptr;
+        if (B <= 0 || n <= 0) return;
+    }
+    uint4* zp = static_cast<uint4*>(zero_p);
+    const long zn16 = zero_p ? (long)(zero_bytes / 16) : 0;
     if (n % 4 == 0)
-        hipLaunchKernelGGL(k_adj_pack, dim3(t, (n + 63) / 64, B), dim3(256), 0, q.stream, A, P, Pt, flag, n, ld);
+        hipLaunchKernelGGL(k_adj_pack, dim3(t, (n + 63) / 64, B), dim3(256), 0, q.stream, A, P, Pt, flag, n, ld, zp,
+                           zn16);
     else
-        hipLaunchKernelGGL(k_adj_pack_any, dim3(t, (n + 63) / 64, B), dim3(256), 0, q.stream, A, P, Pt, flag, n, ld);
+        hipLaunchKernelGGL(k_adj_pack_any, dim3(t, (n + 63) / 64, B), dim3(256), 0, q.stream, A, P, Pt, flag, n, ld,
+                           zp, zn16);
     q.check_launch("adj_pack");
 }
 int adj_pack_ld(int n) { return (n + 7) & ~7; }

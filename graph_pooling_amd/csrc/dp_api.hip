@@ -63,10 +63,10 @@ void ensure_dyn_lds(Seq& q, DynLdsOnce& st, const void* fn, int bytes, const cha
 // dp_model.hip
 int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                     const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
-                    float* assign_out, void* save);
+                    float* assign_out, void* save, int mode);
 int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                      const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
-                     const float* d_assign, float* grads, const void* save);
+                     const float* d_assign, float* grads, const void* save, int prezeroed);
 size_t encoder_save_bytes(const dp_encoder_cfg& c);
 int encoder_validate(const dp_encoder_cfg* c);
 int encoder_save_locate(const dp_encoder_cfg& c, int level, int field, size_t* offset, size_t* count);
@@ -218,25 +218,27 @@ void pool_bwd_seq(Seq& q, const float* S, const float* Z, int ldz, const float* 
 }
 
 void loss_fwd_seq(Seq& q, const float* ypred, const long long* label, const float* S, const float* adj,
-                  const int* num_nodes, float* loss_out, float* prob, int B, int C, int N, int K, int linkpred);
+                  const int* num_nodes, float* loss_out, float* prob, float* dunit, int B, int C, int N, int K,
+                  int linkpred);
 void loss_bwd_seq(Seq& q, const float* prob, const long long* label, const float* S, const float* adj,
                   const int* num_nodes, const float* dloss, float* d_ypred, float* dS, int B, int C, int N, int K,
                   int linkpred) {
-    ce_bwd(q, prob, label, dloss, 1.f, d_ypred, B, C);
+    if (d_ypred) ce_bwd(q, prob, label, dloss, 1.f, d_ypred, B, C);
     if (linkpred) linkpred_bwd(q, S, K, adj, num_nodes, dloss, dS, K, B, N, K, 0);
 }
 
 __global__ void k_add2(float* out, const float* a, const float* b) { out[0] = a[0] + b[0]; out[1] = b[0]; }
 
 void loss_fwd_seq(Seq& q, const float* ypred, const long long* label, const float* S, const float* adj,
-                  const int* num_nodes, float* loss_out, float* prob, int B, int C, int N, int K, int linkpred) {
+                  const int* num_nodes, float* loss_out, float* prob, float* dunit, int B, int C, int N, int K,
+                  int linkpred) {
     float* tmp = q.alloc<float>(64);
     if (q.err) return;
     if (!linkpred) {                       // loss_out = (CE, 0): one launch
-        ce_fwd(q, ypred, label, loss_out, prob, B, C, loss_out + 1);
+        ce_fwd(q, ypred, label, loss_out, prob, B, C, loss_out + 1, dunit);
         return;
     }
-    ce_fwd(q, ypred, label, tmp, prob, B, C);
+    ce_fwd(q, ypred, label, tmp, prob, B, C, nullptr, dunit);
     if (linkpred) {
         linkpred_fwd(q, S, K, adj, num_nodes, tmp + 1, B, N, K);
         if (q.ok()) {
@@ -528,8 +530,8 @@ size_t dp_encoder_save_bytes(const dp_encoder_cfg* cfg) {
 }
 size_t dp_encoder_workspace_bytes(const dp_encoder_cfg* cfg) {
     if (encoder_validate(cfg) != DP_OK) return 0;
-    size_t f = sized([&](Seq& q) { encoder_forward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0); });
-    size_t b = sized([&](Seq& q) { encoder_backward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0); });
+    size_t f = sized([&](Seq& q) { encoder_forward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0, DP_MODE_TRAIN); });
+    size_t b = sized([&](Seq& q) { encoder_backward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0); });
     return f > b ? f : b;
 }
 int dp_encoder_save_locate(const dp_encoder_cfg* cfg, int level, int field, size_t* offset, size_t* count) {
@@ -542,7 +544,7 @@ int dp_encoder_save_locate(const dp_encoder_cfg* cfg, int level, int field, size
 int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
                        const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
                        float* assign_out, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
-                       void* stream) {
+                       int mode, void* stream) {
     int rc = encoder_validate(cfg);
     if (rc != DP_OK) return rc;
     NOTNULL(params); NOTNULL(x); NOTNULL(adj); NOTNULL(ypred); NOTNULL(save);
@@ -550,40 +552,42 @@ int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const flo
     DP_CHECK_ARG(save_bytes >= encoder_save_bytes(*cfg), "save buffer too small: %zu < %zu", save_bytes,
                  encoder_save_bytes(*cfg));
     Seq q(STREAM(stream), workspace, workspace_bytes);
-    return encoder_forward(q, *cfg, params, x, adj, assign_x, num_nodes, dropout, ypred, assign_out, save);
+    DP_CHECK_ARG((mode & ~(DP_MODE_TRAIN)) == 0, "mode=%d: DP_MODE_EVAL or DP_MODE_TRAIN", mode);
+    return encoder_forward(q, *cfg, params, x, adj, assign_x, num_nodes, dropout, ypred, assign_out, save, mode);
 }
 int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
                         const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
                         const float* d_assign, float* grads, const void* save, size_t save_bytes, void* workspace,
-                        size_t workspace_bytes, void* stream) {
+                        size_t workspace_bytes, int prezeroed, void* stream) {
     int rc = encoder_validate(cfg);
     if (rc != DP_OK) return rc;
     NOTNULL(params); NOTNULL(x); NOTNULL(adj); NOTNULL(d_ypred); NOTNULL(grads); NOTNULL(save);
     DP_CHECK_ARG(save_bytes >= encoder_save_bytes(*cfg), "save buffer too small: %zu < %zu", save_bytes,
                  encoder_save_bytes(*cfg));
     Seq q(STREAM(stream), workspace, workspace_bytes);
-    return encoder_backward(q, *cfg, params, x, adj, assign_x, num_nodes, dropout, d_ypred, d_assign, grads, save);
+    return encoder_backward(q, *cfg, params, x, adj, assign_x, num_nodes, dropout, d_ypred, d_assign, grads, save,
+                            prezeroed);
 }
 
 size_t dp_loss_workspace_bytes(int B, int N, int K, int linkpred) {
-    size_t f = sized([&](Seq& q) { loss_fwd_seq(q, 0, 0, 0, 0, 0, 0, 0, B, 1, N, K, linkpred); });
+    size_t f = sized([&](Seq& q) { loss_fwd_seq(q, 0, 0, 0, 0, 0, 0, 0, 0, B, 1, N, K, linkpred); });
     size_t b = sized([&](Seq& q) { loss_bwd_seq(q, 0, 0, 0, 0, 0, 0, 0, 0, B, 1, N, K, linkpred); });
     return f > b ? f : b;
 }
 int dp_loss_forward(const float* ypred, const long long* label, const float* S, const float* adj, const int* num_nodes,
-                    float* loss_out, float* prob, int B, int C, int N, int K, int linkpred, void* workspace,
-                    size_t workspace_bytes, void* stream) {
+                    float* loss_out, float* prob, float* d_ypred_unit, int B, int C, int N, int K, int linkpred,
+                    void* workspace, size_t workspace_bytes, void* stream) {
     NOTNULL(ypred); NOTNULL(label); NOTNULL(loss_out); NOTNULL(prob);
     NONNEG(B); NONNEG(C);
     DP_CHECK_ARG(!linkpred || (S && adj && N > 0 && K > 0), "linkpred needs S, adj, N, K");
     Seq q(STREAM(stream), workspace, workspace_bytes);
-    loss_fwd_seq(q, ypred, label, S, adj, num_nodes, loss_out, prob, B, C, N, K, linkpred);
+    loss_fwd_seq(q, ypred, label, S, adj, num_nodes, loss_out, prob, d_ypred_unit, B, C, N, K, linkpred);
     return q.err;
 }
 int dp_loss_backward(const float* prob, const long long* label, const float* S, const float* adj, const int* num_nodes,
                      const float* dloss, float* d_ypred, float* dS, int B, int C, int N, int K, int linkpred,
                      void* workspace, size_t workspace_bytes, void* stream) {
-    NOTNULL(prob); NOTNULL(label); NOTNULL(d_ypred);
+    NOTNULL(prob); NOTNULL(label);
     NONNEG(B); NONNEG(C);
     DP_CHECK_ARG(!linkpred || (S && adj && dS && N > 0 && K > 0), "linkpred needs S, adj, dS, N, K");
     Seq q(STREAM(stream), workspace, workspace_bytes);

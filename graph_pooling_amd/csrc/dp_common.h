@@ -71,6 +71,11 @@ struct Seq {
     int err;             // 0, DP_ERR_* (<0) or hipError_t (>0)
     bool dry;            // dry run: only walk the allocations (workspace sizing), launch nothing
     const int* pred = nullptr;   // when set: bgemm launches exit at once unless *pred != 0 (device-side fallback gate)
+    // a small region (16-byte aligned, a multiple of 16 bytes, <= 4 KiB) the NEXT bgemm_group launch clears with its
+    // first workgroup — saves the zero-fill launch in front of a kernel that needs a cleared flag / ticket block.
+    // Whoever sets it must let a GEMM follow before the region's first reader (bgemm_group consumes and clears it).
+    void* fold_zero_p = nullptr;
+    int fold_zero_n16 = 0;
 
     Seq(hipStream_t s, void* w, size_t wb) : stream(s), ws((char*)w), ws_bytes(wb), ws_off(0), err(0), dry(false) {}
     static Seq sizing() {
@@ -250,7 +255,8 @@ void masked_max_bwd(Seq& q, const float* dout, int ldo, const int* argmax, int l
                     int n, int F);
 void relu_bwd_inplace(Seq& q, float* d, const float* h, long count);
 void ce_fwd(Seq& q, const float* logits, const long long* label, float* loss, float* prob, int B, int C,
-            float* also_zero = nullptr /*a second scalar to clear in the same launch*/);
+            float* also_zero = nullptr /*a second scalar to clear in the same launch*/,
+            float* dunit = nullptr /*[B, C]: d loss / d logits for an upstream gradient of 1*/);
 void ce_bwd(Seq& q, const float* prob, const long long* label, const float* dloss, float scale, float* dlogits,
             int B, int C);
 void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, long count, int accumulate);
@@ -267,7 +273,11 @@ struct PackedAdj {               // written by adj_pack: bf16 copies of A and A^
     int ld;                      // adj_pack_ld(n)
     const int* flag;             // device int: 0 = every entry of A is exactly representable in bf16
 };
-void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int* flag, int B, int n, int ld);
+// flag_zeroed: the 256-byte flag block was already cleared in stream order (Seq::fold_zero_p through a GEMM);
+// zero_p / zero_bytes: an unrelated region the pack kernel's workgroups clear on the side (the backward pass's
+// accumulators: an HBM-bound kernel with 1000+ workgroups absorbs a few MB of stores for free)
+void adj_pack(Seq& q, const float* A, unsigned short* P, unsigned short* Pt, int* flag, int B, int n, int ld,
+              bool flag_zeroed = false, void* zero_p = nullptr, size_t zero_bytes = 0);
 int adj_pack_ld(int n);
 bool adj_pack_supported(int n, int C);
 size_t split3_elems(int B, int n, int C);

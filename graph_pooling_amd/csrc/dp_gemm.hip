@@ -383,6 +383,8 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, int ks, float* lds
 // One launch, up to GEMM_GROUP_MAX independent problems (same batch count): the workgroup finds its
 // problem from the tile prefix, then runs the body for that problem's transposes.
 struct GemmGroupArgs {
+    uint4* zero_p;       // non-null: workgroup (0, 0) clears zero_n16 16-byte words (Seq::fold_zero_p)
+    int zero_n16;
     const int* pred;     // non-null: run only when *pred != 0
     int count;
     int stamp_slot;      // diagnostic build only
@@ -398,6 +400,8 @@ template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void bgemm_kernel(GemmGroupArgs g) {
     __shared__ __attribute__((aligned(16))) float
         lds[cmax(lds_size<BM, true>(), lds_size<BM, false>()) + cmax(lds_size<BN, true>(), lds_size<BN, false>()) + 8];
+    if (g.zero_p && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < g.zero_n16; i += 256) g.zero_p[i] = make_uint4(0, 0, 0, 0);
     if (g.pred && __builtin_amdgcn_readfirstlane(*g.pred) == 0) return;
     if (threadIdx.x == 0) GEMM_STAMP_MIN(g.stamp_slot);
     GEMM_STAMP(g.stamp_slot, 2);
@@ -467,6 +471,10 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
     }
     GemmGroupArgs g{};
     g.pred = q.pred;
+    if (q.fold_zero_p && !q.pred) {      // (a predicated launch may not run at all: leave it for an unconditional one)
+        g.zero_p = static_cast<uint4*>(q.fold_zero_p);
+        g.zero_n16 = q.fold_zero_n16;
+    }
     int maxN = 0;
     for (int i = 0; i < count; ++i) {
         const GemmDesc& s = d[i];
@@ -484,6 +492,7 @@ void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
         if (s.N > maxN) maxN = s.N;
     }
     if (g.count == 0) return;
+    if (g.zero_p) q.fold_zero_p = nullptr, q.fold_zero_n16 = 0;
     if (knobs().gemm_trace) {   // host-side shape log, one line per launch
         fprintf(stderr, "bgemm batch=%d ksplit=%d:", batch, ksplit);
         for (int i = 0; i < g.count; ++i)

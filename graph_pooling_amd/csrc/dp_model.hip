@@ -215,6 +215,36 @@ int node_ksplit(const dp_encoder_cfg& c) {
     return ks < 1 ? 1 : (ks > 8 ? 8 : ks);
 }
 
+// The backward pass's zero-initialised accumulators — level gradient buffers and the per-graph parameter-gradient
+// slabs (atomic bias sums; unused split-K rows) — are ONE block at the very start of the workspace in BOTH walks, so a
+// training forward can clear it on the side of its adjacency-pack kernel and the backward pass starts without a
+// zero-fill launch.
+struct LevelGrad {
+    float* dZe;    // [B, n, D]
+    float* dZa;    // [B, n, Da]
+    float* dX0;    // [B, n, dims_e[0]] gradient w.r.t. the level input (levels >= 1), accumulated
+    float* dAdj;   // [B, n, n] (levels >= 1), accumulated
+};
+struct BwdZero {
+    LevelGrad gr[DP_MAX_LEVELS + 1];
+    float* slabs;
+    size_t begin, end;
+};
+BwdZero alloc_bwd_zero(Seq& q, const dp_encoder_cfg& c) {
+    BwdZero z{};
+    z.begin = q.ws_off;
+    for (int j = 0; j <= c.num_pooling; ++j) {
+        const LevelInfo li = level_info(c, j);
+        const size_t rows = (size_t)c.B * li.n;
+        z.gr[j].dZe = q.alloc<float>(rows * li.D);
+        z.gr[j].dX0 = j >= 1 ? q.alloc<float>(rows * li.e->dims[0]) : nullptr;
+        z.gr[j].dAdj = j >= 1 ? q.alloc<float>(rows * li.n) : nullptr;
+    }
+    z.slabs = q.alloc<float>((size_t)c.B * node_ksplit(c) * (c.n_graph_params > 0 ? c.n_graph_params : 1));
+    z.end = q.ws_off;
+    return z;
+}
+
 bool level_is_small(int B, const LevelInfo& li) {
     if (li.G != 1) return false;
     for (int l = 0; l < li.L; ++l)
@@ -222,7 +252,19 @@ bool level_is_small(int B, const LevelInfo& li) {
     return true;
 }
 
+// the level-0 adjacency pack, run right AFTER the first transform GEMM of the level: that GEMM does not read the
+// adjacency and clears the pack flag on the side (Seq::fold_zero_p), so the flag needs no launch of its own
+struct PackJob {
+    const float* adj;
+    unsigned short *pkA, *pkAt;
+    int* flag;
+    int ld;
+    void* zero_p;        // backward accumulators to clear on the side (training forward), or null
+    size_t zero_bytes;
+};
+
 struct LevelIO {
+    const PackJob* pack = nullptr;
     const float* x0e;  // embed stack input [B, n, dims_e[0]]
     const float* x0a;  // assign stack input [B, n, dims_a[0]]
     const float* adj;  // [B, n, n]
@@ -300,7 +342,18 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
         const bool last = l == li.L - 1;
         // with a packed adjacency the transform GEMM also emits the 3-plane bf16 split the aggregation reads
         const bool presplit = pk && vs && aggregate_packed_usable(io.adj, n, ct);
+        if (l == 0 && io.pack) {
+            q.fold_zero_p = io.pack->flag;
+            q.fold_zero_n16 = 16;
+        }
         transform(q, c, li, lv, io, params, l, Pj, presplit ? vs : nullptr);
+        if (l == 0 && io.pack) {
+            const bool folded = q.fold_zero_p == nullptr;      // consumed by the GEMM launch
+            q.fold_zero_p = nullptr;
+            q.fold_zero_n16 = 0;
+            adj_pack(q, io.pack->adj, io.pack->pkA, io.pack->pkAt, io.pack->flag, B, n, io.pack->ld, folded,
+                     io.pack->zero_p, io.pack->zero_bytes);
+        }
         RowGroups g = groups_of(li, l);
         GroupCPtrs bias{};
         bias.p[0] = PW(params, li.e->b_off[l]);
@@ -336,13 +389,6 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
         }
     }
 }
-
-struct LevelGrad {
-    float* dZe;    // [B, n, D]
-    float* dZa;    // [B, n, Da]
-    float* dX0;    // [B, n, dims_e[0]] gradient w.r.t. the level input (levels >= 1), accumulated
-    float* dAdj;   // [B, n, n] (levels >= 1), accumulated
-};
 
 void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
                     const float* params, const LevelGrad& gr, float* slabs, long slab_stride, int KS, float* Pj,
@@ -562,16 +608,25 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
 
 int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                     const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
-                    float* assign_out, void* save) {
+                    float* assign_out, void* save, int mode) {
     SaveLayout sv = layout_save(c, save);
+    const BwdZero bz = alloc_bwd_zero(q, c);      // same offsets as in encoder_backward: first block of the workspace
     Scratch sc = fwd_scratch(q, c);
     if (q.err) return q.err;
     const int B = c.B, P = c.num_pooling;
     const int ldfeat = c.pred_dims[0];
-    // one pass over the level-0 adjacency: bf16 copies of A and A^T + exactness flag (used by every later pass)
+    const bool train = (mode & DP_MODE_TRAIN) != 0;
+    // one pass over the level-0 adjacency: bf16 copies of A and A^T + exactness flag (used by every later pass); it
+    // runs behind the level's first transform GEMM (see PackJob) and, in a training forward, clears the backward
+    // pass's accumulators on the side
     PackedAdj pk0{sv.pkA, sv.pkAt, sv.pk_ld, sv.pk_flag};
     const PackedAdj* pkp = sv.pkA ? &pk0 : nullptr;
-    if (pkp) adj_pack(q, adj, sv.pkA, sv.pkAt, sv.pk_flag, B, c.N, sv.pk_ld);
+    PackJob pack{adj, sv.pkA, sv.pkAt, sv.pk_flag, sv.pk_ld, train && !q.dry ? q.ws + bz.begin : nullptr,
+                 train ? bz.end - bz.begin : 0};
+    const bool pack_in_level = pkp && !(level_is_small(B, level_info(c, 0)) && !dropout);
+    if (pkp && !pack_in_level) adj_pack(q, adj, sv.pkA, sv.pkAt, sv.pk_flag, B, c.N, sv.pk_ld, false, pack.zero_p,
+                                        pack.zero_bytes);
+    else if (!pkp && train && !q.dry) zero_fill(q, q.ws + bz.begin, bz.end - bz.begin);
     int featoff = 0;
     const bool fused_head = head_usable(c);
     HeadArgs head = head_args(c, sv, params, ypred);
@@ -585,6 +640,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
         io.drop = dropout;
         io.xm[0] = sc.xm[0];
         io.xm[1] = sc.xm[1];
+        io.pack = (j == 0 && pack_in_level) ? &pack : nullptr;
         level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part, sc.part_b, j == 0 ? pkp : nullptr, sc.vs);
         const int* nn_j = (j == 0) ? num_nodes : nullptr;
         if (c.readout == 0) {
@@ -658,25 +714,18 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
 
 int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                      const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
-                     const float* d_assign, float* grads, const void* save) {
+                     const float* d_assign, float* grads, const void* save, int prezeroed) {
     SaveLayout sv = layout_save(c, (void*)save);
     const int B = c.B, P = c.num_pooling;
     // ---- workspace walk
     size_t maxPU = 0, maxPart = 0, maxSK = 0, maxMeans = 0;
+    // zero-initialised gradient accumulators + slabs: ONE block at the start of the workspace (alloc_bwd_zero)
+    const BwdZero bz = alloc_bwd_zero(q, c);
     LevelGrad gr[DP_MAX_LEVELS + 1]{};
-    // zero-initialised gradient accumulators are carved from ONE block (one memset)
-    const size_t zero_begin = q.ws_off;
-    for (int j = 0; j <= P; ++j) {
-        const LevelInfo li = level_info(c, j);
-        const size_t rows = (size_t)B * li.n;
-        gr[j].dZe = q.alloc<float>(rows * li.D);
-        gr[j].dX0 = j >= 1 ? q.alloc<float>(rows * li.e->dims[0]) : nullptr;
-        gr[j].dAdj = j >= 1 ? q.alloc<float>(rows * li.n) : nullptr;
-    }
-    // ... and so are the gradient slabs (atomic bias sums; unused split-K rows), so they sit in the same block
+    for (int j = 0; j <= P; ++j) gr[j] = bz.gr[j];
     const int KS = node_ksplit(c);
-    float* slabs = q.alloc<float>((size_t)B * KS * (c.n_graph_params > 0 ? c.n_graph_params : 1));
-    const size_t zero_end = q.ws_off;
+    float* slabs = bz.slabs;
+    const size_t zero_begin = bz.begin, zero_end = bz.end;
     for (int j = 0; j <= P; ++j) {
         const LevelInfo li = level_info(c, j);
         const size_t rows = (size_t)B * li.n;
@@ -715,7 +764,8 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     // every entry of `grads` is written below (weights: slab reduce / direct GEMM; biases: reduce_bias /
     // column sums), so no memset of it is needed
     // (one launch: level gradient accumulators + the slabs, which receive atomic adds and leave split-K rows unused)
-    zero_fill(q, q.ws + zero_begin, zero_end - zero_begin);
+    // (a training forward with this workspace already cleared it on the side of its adjacency pack: prezeroed)
+    if (!prezeroed) zero_fill(q, q.ws + zero_begin, zero_end - zero_begin);
     const bool fused_head = head_usable(c);
     if (fused_head) {
         // pred_model backward + the max-readout scatter of every level in one launch

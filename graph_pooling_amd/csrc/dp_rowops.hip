@@ -988,8 +988,11 @@ void axpy(Seq& q, float* y, const float* x, float a, long count) {
 
 // ------------------------------------------------------------------ cross entropy
 // loss = mean_b (logsumexp(logits_b) - logits_b[label_b])   (F.cross_entropy, encoders.py:1127)
+// dunit (optional): d loss / d logits for a unit upstream gradient, (softmax - onehot) / B — the gradient the
+// reference's `loss.backward()` (train.py:208) sends down; writing it here lets the backward pass start at the
+// prediction head without a launch of its own.
 __global__ __launch_bounds__(256) void k_ce_fwd(const float* logits, const long long* label, float* loss,
-                                                float* prob, int B, int C, float* also_zero) {
+                                                float* prob, int B, int C, float* also_zero, float* dunit) {
     __shared__ float red[256];
     float acc = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
@@ -1003,6 +1006,9 @@ __global__ __launch_bounds__(256) void k_ce_fwd(const float* logits, const long 
         acc += lse - l[y];
         if (prob)
             for (int c = 0; c < C; ++c) prob[(long)b * C + c] = expf(l[c] - lse);
+        if (dunit)
+            for (int c = 0; c < C; ++c)
+                dunit[(long)b * C + c] = (expf(l[c] - lse) - (y == c ? 1.f : 0.f)) / (float)B;
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -1016,9 +1022,9 @@ __global__ __launch_bounds__(256) void k_ce_fwd(const float* logits, const long 
     }
 }
 void ce_fwd(Seq& q, const float* logits, const long long* label, float* loss, float* prob, int B, int C,
-            float* also_zero) {
+            float* also_zero, float* dunit) {
     if (!q.ok()) return;
-    hipLaunchKernelGGL(k_ce_fwd, dim3(1), dim3(256), 0, q.stream, logits, label, loss, prob, B, C, also_zero);
+    hipLaunchKernelGGL(k_ce_fwd, dim3(1), dim3(256), 0, q.stream, logits, label, loss, prob, B, C, also_zero, dunit);
     q.check_launch("ce_fwd");
 }
 __global__ void k_ce_bwd(const float* prob, const long long* label, const float* dloss, float scale, float* dl,

@@ -139,7 +139,12 @@ class _EncoderFn(torch.autograd.Function):
         _lib.check(lib.dp_encoder_forward(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(), adj.data_ptr(),
                                           _lib.ptr(assign_x), _lib.ptr(num_nodes), _lib.ptr(drop), ypred.data_ptr(),
                                           _lib.ptr(assign), save.data_ptr(), plan.save_bytes,
-                                          plan.workspace.data_ptr(), plan.ws_bytes, stream), "dp_encoder_forward")
+                                          plan.workspace.data_ptr(), plan.ws_bytes,
+                                          _lib.MODE_TRAIN if needs_grad else _lib.MODE_EVAL, stream),
+                   "dp_encoder_forward")
+        # a training forward cleared the backward accumulators in the plan's workspace: the FIRST backward of the most
+        # recent training forward may skip its zero-fill (any other backward clears them itself)
+        plan.prezero_owner = ctx if needs_grad else None
         ctx.owner, ctx.plan, ctx.save = owner, plan, save
         owner._last_save = (plan, save)
         ctx.inputs = (x, adj, assign_x, num_nodes, drop)
@@ -159,10 +164,12 @@ class _EncoderFn(torch.autograd.Function):
         if d_assign is not None:
             d_assign = d_assign.contiguous()
         grads = torch.empty(plan.cfg.n_params, device=x.device, dtype=torch.float32)
+        prezeroed = 1 if plan.prezero_owner is ctx else 0
+        plan.prezero_owner = None
         _lib.check(lib.dp_encoder_backward(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(), adj.data_ptr(),
                                            _lib.ptr(assign_x), _lib.ptr(num_nodes), _lib.ptr(drop), d_ypred.data_ptr(),
                                            _lib.ptr(d_assign), grads.data_ptr(), ctx.save.data_ptr(),
-                                           plan.save_bytes, plan.workspace.data_ptr(), plan.ws_bytes,
+                                           plan.save_bytes, plan.workspace.data_ptr(), plan.ws_bytes, prezeroed,
                                            _lib.current_stream()), "dp_encoder_backward")
         owner._last_flat_grad = grads
         out = [None, None, None, None, None, None]
@@ -185,6 +192,7 @@ class _Plan:
             _lib.check(-1, "dp_encoder_save_bytes / dp_encoder_workspace_bytes")
         self.workspace = torch.empty(self.ws_bytes, device=device, dtype=torch.uint8)
         self._eval_save = None
+        self.prezero_owner = None
         self.device = device
 
     def eval_save(self):
@@ -483,6 +491,40 @@ class GcnEncoderGraph(nn.Module):
 
 
 # ----------------------------------------------------------------------------- loss
+_UNIT_SEED = {}          # device -> the scalar 1.0 that seeds loss.backward()
+
+
+def _unit_seed(device):
+    """A cached device scalar 1.0.  `loss.backward()` (train.py:208) seeds the backward pass with ones_like(loss) — a
+    fill launch per step; `_Loss.backward` hands autograd this tensor instead, and `_LossFn.backward` recognises it by
+    address, so the gradient (softmax - onehot) / B that the loss kernel already wrote goes to the prediction head
+    as it is: no seed fill, no cross-entropy backward launch."""
+    t = _UNIT_SEED.get(device)
+    if t is None:
+        if device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return None            # GPU path only; never allocate the cached scalar from a graph's private pool
+        t = torch.ones((), device=device, dtype=torch.float32)
+        _UNIT_SEED[device] = t
+    return t
+
+
+class _Loss(torch.Tensor):
+    """The loss tensor `model.loss()` returns: an ordinary tensor whose parameterless `.backward()` seeds autograd with
+    the cached unit scalar (see _unit_seed).  Every other operation returns plain tensors."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        with torch._C.DisableTorchFunctionSubclass():
+            if func is torch.Tensor.backward and len(args) == 1 and kwargs.get("gradient") is None \
+                    and args[0].dim() == 0 and args[0].dtype == torch.float32:
+                seed = _unit_seed(args[0].device)
+                if seed is not None:
+                    kwargs = dict(kwargs)
+                    kwargs["gradient"] = seed
+            return func(*args, **kwargs)
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, label, S, adj, num_nodes, linkpred):
@@ -500,11 +542,12 @@ class _LossFn(torch.autograd.Function):
         ws = torch.empty(wsb, device=pred.device, dtype=torch.uint8)
         out = torch.empty(2, device=pred.device, dtype=torch.float32)
         prob = torch.empty(B, Cc, device=pred.device, dtype=torch.float32)
+        dunit = torch.empty(B, Cc, device=pred.device, dtype=torch.float32)
         _lib.check(lib.dp_loss_forward(pred.data_ptr(), label.data_ptr(), _lib.ptr(S) if linkpred else None,
                                        _lib.ptr(adj) if linkpred else None, _lib.ptr(num_nodes),
-                                       out.data_ptr(), prob.data_ptr(), B, Cc, N, K, int(linkpred),
+                                       out.data_ptr(), prob.data_ptr(), dunit.data_ptr(), B, Cc, N, K, int(linkpred),
                                        ws.data_ptr(), wsb, _lib.current_stream()), "dp_loss_forward")
-        ctx.saved = (prob, label, S if linkpred else None, adj if linkpred else None, num_nodes, ws)
+        ctx.saved = (prob, dunit, label, S if linkpred else None, adj if linkpred else None, num_nodes, ws)
         ctx.dims = (B, Cc, N, K, bool(linkpred))
         total, link = out[0], out[1]
         ctx.mark_non_differentiable(link)
@@ -514,15 +557,20 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dtotal, _dlink):
         lib = _lib.load()
-        prob, label, S, adj, num_nodes, ws = ctx.saved
+        prob, dunit, label, S, adj, num_nodes, ws = ctx.saved
         B, Cc, N, K, linkpred = ctx.dims
         if dtotal is None:
             return None, None, None, None, None, None
+        seed = _UNIT_SEED.get(dtotal.device)
+        unit = seed is not None and dtotal.data_ptr() == seed.data_ptr() and dtotal.dim() == 0
+        if unit and not linkpred:
+            return dunit, None, None, None, None, None     # written by the loss kernel: nothing to launch
         dtotal = dtotal.contiguous().float()
-        dpred = torch.empty(B, Cc, device=prob.device, dtype=torch.float32)
+        dpred = dunit if unit else torch.empty(B, Cc, device=prob.device, dtype=torch.float32)
         dS = torch.empty_like(S) if linkpred else None
         _lib.check(lib.dp_loss_backward(prob.data_ptr(), label.data_ptr(), _lib.ptr(S), _lib.ptr(adj),
-                                        _lib.ptr(num_nodes), dtotal.data_ptr(), dpred.data_ptr(), _lib.ptr(dS),
+                                        _lib.ptr(num_nodes), None if unit else dtotal.data_ptr(),
+                                        None if unit else dpred.data_ptr(), _lib.ptr(dS),
                                         B, Cc, N, K, int(linkpred), ws.data_ptr(), ws.numel(),
                                         _lib.current_stream()), "dp_loss_backward")
         return dpred, None, dS, None, None, None
@@ -533,7 +581,8 @@ def _loss(owner, pred, label, S, adj, batch_num_nodes, linkpred):
     total, link = _LossFn.apply(pred, label, S, adj, nn_dev, linkpred)
     if linkpred:
         owner.link_loss = link
-    return total
+    _unit_seed(pred.device)                   # make sure the cached seed exists before anyone captures a graph
+    return total.as_subclass(_Loss) if total.requires_grad else total
 
 
 # ----------------------------------------------------------------------------- Set2Set encoder

@@ -252,23 +252,34 @@ int dp_encoder_save_locate(const dp_encoder_cfg* cfg, int level, int field, size
  * P = 0; `save` keeps activations for backward.  dropout: the mask buffer addressed by the stacks' drop_off
  * (training with GraphConv dropout > 0; the caller draws the masks and passes the SAME buffer to backward), or
  * NULL (evaluation, or dropout 0: every drop_off is ignored). */
+#define DP_MODE_EVAL 0   /* forward only (train.py:30-58 evaluate): nothing is prepared for a backward pass */
+#define DP_MODE_TRAIN 1  /* a dp_encoder_backward with the SAME save and workspace buffers will follow: the forward also
+                            clears the backward pass's accumulators (they live at the start of the workspace) on the side
+                            of its adjacency-pack kernel, so the backward may be called with prezeroed = 1 — provided
+                            nothing else used that workspace in between and it is the first backward of this forward */
 int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
                        const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
-                       float* assign_out, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+                       float* assign_out, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
+                       int mode, void* stream);
 /* d_ypred [B,label_dim]; d_assign [B,N,K_0] or NULL (gradient arriving at the level-0 assignment
- * from the link-prediction loss); grads: flat, same layout as params, OVERWRITTEN. */
+ * from the link-prediction loss); grads: flat, same layout as params, OVERWRITTEN.
+ * prezeroed: 1 iff the accumulators were cleared by a DP_MODE_TRAIN forward (see above); 0: this call clears them. */
 int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
                         const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
                         const float* d_assign, float* grads, const void* save, size_t save_bytes,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        void* workspace, size_t workspace_bytes, int prezeroed, void* stream);
 
 /* SoftPoolingGcnEncoder.loss (encoders.py:1302-1334): loss_out[0] = CE (+ link), loss_out[1] = link.
- * prob [B,C] saved for backward.  S / adj may be NULL when linkpred == 0. */
+ * prob [B,C] saved for backward.  S / adj may be NULL when linkpred == 0.
+ * d_ypred_unit [B,C] (may be NULL): d loss / d ypred for an upstream gradient of 1, (softmax - onehot) / B, written by
+ * the same launch — `loss.backward()` (train.py:208) sends exactly that down, so the caller can hand it to
+ * dp_encoder_backward without a gradient launch of its own. */
 size_t dp_loss_workspace_bytes(int B, int N, int K, int linkpred);
 int dp_loss_forward(const float* ypred, const long long* label, const float* S, const float* adj,
-                    const int* num_nodes, float* loss_out, float* prob, int B, int C, int N, int K,
-                    int linkpred, void* workspace, size_t workspace_bytes, void* stream);
-/* dloss: device scalar (NULL = 1).  d_ypred [B,C], dS [B,N,K] (only when linkpred) overwritten. */
+                    const int* num_nodes, float* loss_out, float* prob, float* d_ypred_unit, int B, int C, int N,
+                    int K, int linkpred, void* workspace, size_t workspace_bytes, void* stream);
+/* dloss: device scalar (NULL = 1).  d_ypred [B,C] (NULL: not wanted — the caller uses d_ypred_unit), dS [B,N,K]
+ * (only when linkpred) overwritten. */
 int dp_loss_backward(const float* prob, const long long* label, const float* S, const float* adj,
                      const int* num_nodes, const float* dloss, float* d_ypred, float* dS, int B, int C,
                      int N, int K, int linkpred, void* workspace, size_t workspace_bytes, void* stream);

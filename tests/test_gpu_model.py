@@ -52,16 +52,22 @@ def test_softpool_against_reference_golden(name, golden):
     try:
         grads_close(model, grads)
     except AssertionError:
-        # A max-readout tie resolved differently from the reference's own run (tests/parity.py): legitimate only if
-        # (a) the oracle with ITS OWN arg-max reproduces the reference's gradients (the fixture pins the oracle) and
-        # (b) the HIP gradients equal the oracle's with the HIP winners forced, and (c) the winners really differ.
-        _, inter_f, _, g_free = _oracle_run(params, x, adj, a["num_nodes"], T(a["label"]), linkpred)
-        for k, g in grads.items():
-            close(g_free[k], g, 1e-3, max(1e-7, 2e-5 * float(g.abs().max())))
-        _, inter_w, _, g_forced = _oracle_run(params, x, adj, a["num_nodes"], T(a["label"]), linkpred, winners=win)
-        close(inter_w["readout"], inter_f["readout"], 1e-5, 2e-6)
-        grads_close(model, g_forced)
-        assert any(float((g_forced[k] - g_free[k]).abs().max()) > 0 for k in grads), "no tie flip explains the mismatch"
+        # Not within rtol 1e-3 of the reference's fp32 numbers.  Two legitimate reasons exist (tests/parity.py): a
+        # max-readout tie resolved differently, or an ill-conditioned entry (a bias gradient in front of a BatchNorm is
+        # a sum that nearly cancels: torch-CPU on another host already moves it by 3e-3).  Either way the claim that
+        # matters is checked against an fp64 run of the oracle with the HIP winners forced: the HIP gradient must be
+        # no further from it than 4x the reference's own fp32 gradient is.
+        Pm = {k: v.clone().double().requires_grad_(True) for k, v in params.items()}
+        yo, inter = O.softpool_forward(Pm, x.double(), adj.double(), a["num_nodes"], x.double(), winners=win)
+        lo, _ = O.softpool_loss(yo, T(a["label"]), inter["assign_0"], adj.double(), a["num_nodes"], linkpred)
+        lo.backward()
+        close(yo, a["ypred"])                              # the forced winners hold the maximum: same forward
+        for k, p in model.named_parameters():
+            g64 = Pm[k].grad
+            e_gpu = float((p.grad.detach().cpu().double() - g64).abs().max())
+            e_ref = float((grads[k].double() - g64).abs().max())
+            assert e_gpu <= 4 * e_ref + 1e-7 * float(g64.abs().max()), \
+                f"{k}: |hip - fp64| {e_gpu:.3e} against the reference's own |fp32 - fp64| {e_ref:.3e}"
 
 
 @pytest.mark.parametrize("tag", ["concat", "addself", "nobn"])
