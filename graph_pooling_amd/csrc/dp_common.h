@@ -302,6 +302,30 @@ void small_gcn_bwd(Seq& q, const float* adj, const float* xin, int ldxin, const 
                    float* db, long slab_stride, int B, int n, int din, int dout, int add_self, int has_bn,
                    int has_relu);
 
+// whole-level variants: every layer of the level's stack in ONE launch per direction (grid barrier between layers
+// for the cross-graph BatchNorm statistics).  ld / offsets as the per-layer calls would pass them.
+struct SmallLevelIO {
+    const float* adj;              // [B, n, n]
+    const float* x0;               // level input [B, n, dims[0]]
+    int ldx0;
+    const float* params;
+    long w_off[DP_MAX_LAYERS], b_off[DP_MAX_LAYERS];
+    float* Y[DP_MAX_LAYERS];       // non-last layers: normalised pre-ReLU output, ld ldY[l]; null for the last layer
+    int ldY[DP_MAX_LAYERS];
+    float* invn[DP_MAX_LAYERS];    // [B, n]
+    float* stats[DP_MAX_LAYERS];   // [n, 2] of the non-last layers
+    float* Ze;                     // concat buffer [B, n, ldz], slice l at column coff[l]
+    int ldz;
+    int coff[DP_MAX_LAYERS];
+    float* part;                   // exchange scratch, small_level_part_floats() floats
+    int* bar;                      // 2 ints: ticket (zeroed in stream order before the launch), error word
+};
+bool small_level_fused_ok(int B, int n, const int* dims, int L, bool dadj);
+size_t small_level_part_floats(int B, int n, int L);
+void small_level_fwd(Seq& q, const SmallLevelIO& io, int B, int n, const int* dims, int L, int add_self, int bn);
+void small_level_bwd(Seq& q, const SmallLevelIO& io, const float* dZe, float* dX0, float* dadj, float* slabs,
+                     long slab_stride, int B, int n, const int* dims, int L, int add_self, int bn);
+
 // (dp_head.hip) last-level max readout + pred_model in one launch per direction
 struct HeadArgs {
     const float* Z;          // last level's embedding [B, n, ldz] for the in-kernel max readout, or null

@@ -228,6 +228,7 @@ struct LevelGrad {
 struct BwdZero {
     LevelGrad gr[DP_MAX_LEVELS + 1];
     float* slabs;
+    int* bar;          // grid-barrier tickets of the whole-level backward kernels: 64 ints per level
     size_t begin, end;
 };
 BwdZero alloc_bwd_zero(Seq& q, const dp_encoder_cfg& c) {
@@ -241,6 +242,7 @@ BwdZero alloc_bwd_zero(Seq& q, const dp_encoder_cfg& c) {
         z.gr[j].dAdj = j >= 1 ? q.alloc<float>(rows * li.n) : nullptr;
     }
     z.slabs = q.alloc<float>((size_t)c.B * node_ksplit(c) * (c.n_graph_params > 0 ? c.n_graph_params : 1));
+    z.bar = q.alloc<int>(64 * (DP_MAX_LEVELS + 1));
     z.end = q.ws_off;
     return z;
 }
@@ -284,6 +286,46 @@ bool level_has_dropout(const LevelInfo& li, const LevelIO& io) {
     return false;
 }
 
+// every layer of a small level in one launch per direction (dp_small.hip, whole-level kernels)
+bool level_is_fused(const dp_encoder_cfg& c, const LevelInfo& li, const LevelIO& io, bool dadj) {
+    return level_is_small(c.B, li) && !level_has_dropout(li, io) &&
+           small_level_fused_ok(c.B, li.n, li.e->dims, li.L, dadj);
+}
+// exchange scratch of the whole-level kernels over all levels that may use them
+size_t level_part_floats(const dp_encoder_cfg& c) {
+    size_t mx = 64;
+    for (int j = 0; j <= c.num_pooling; ++j) {
+        const LevelInfo li = level_info(c, j);
+        if (li.G == 1 && li.n <= 64) {
+            const size_t f = small_level_part_floats(c.B, li.n, li.L);
+            mx = f > mx ? f : mx;
+        }
+    }
+    return mx;
+}
+SmallLevelIO small_level_io(const LevelInfo& li, const LevelSave& lv, const LevelIO& io, const float* params,
+                            float* part, int* bar) {
+    SmallLevelIO s{};
+    s.adj = io.adj;
+    s.x0 = io.x0e;
+    s.ldx0 = li.e->dims[0];
+    s.params = params;
+    for (int l = 0; l < li.L; ++l) {
+        s.w_off[l] = li.e->w_off[l];
+        s.b_off[l] = li.e->b_off[l];
+        s.Y[l] = l < li.L - 1 ? lv.layer[l].Y : nullptr;
+        s.ldY[l] = li.ctot[l];
+        s.invn[l] = lv.layer[l].invn;
+        s.stats[l] = lv.layer[l].stats;
+        s.coff[l] = li.coff_e[l];
+    }
+    s.Ze = lv.Ze;
+    s.ldz = li.D;
+    s.part = part;
+    s.bar = bar;
+    return s;
+}
+
 // P = [x_e W_e | x_a W_a]  for layer l of level li  (one grouped launch)
 void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
                const float* params, int l, float* Pj, unsigned short* vs_split = nullptr) {
@@ -317,10 +359,15 @@ void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const Level
 
 void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
                    const float* params, float* Pj, float* Uj, float* part, float* part_b, const PackedAdj* pk,
-                   unsigned short* vs) {
+                   unsigned short* vs, float* lvl_part, int* bar /*zeroed in stream order, or null*/) {
     const int B = c.B, n = li.n;
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
+    if (bar && level_is_fused(c, li, io, true)) {
+        small_level_fwd(q, small_level_io(li, lv, io, params, lvl_part, bar), B, n, li.e->dims, li.L, add_self ? 1 : 0,
+                        bn ? 1 : 0);
+        return;
+    }
     if (level_is_small(B, li) && !level_has_dropout(li, io)) {
         // pooled level (or tiny graphs): one launch per layer, one workgroup per graph (dp_small.hip)
         float* pbuf[2] = {part, part_b};
@@ -393,12 +440,17 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
 void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
                     const float* params, const LevelGrad& gr, float* slabs, long slab_stride, int KS, float* Pj,
                     float* dUj, float* Gj, float* part, float* part_b, const PackedAdj* pk, unsigned short* vs,
-                    float* const dxm[2]) {
+                    float* const dxm[2], float* lvl_part, int* bar) {
     const int B = c.B, n = li.n;
     const long gstride = slab_stride * KS;     // slab rows of one graph: KS split-K partials
     const int ks_level = n >= 256 ? KS : 1;
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
+    if (lvl_part && bar && level_is_fused(c, li, io, true)) {
+        small_level_bwd(q, small_level_io(li, lv, io, params, lvl_part, bar), gr.dZe, gr.dX0, gr.dAdj, slabs, gstride,
+                        B, n, li.e->dims, li.L, add_self ? 1 : 0, bn ? 1 : 0);
+        return;
+    }
     if (level_is_small(B, li) && !level_has_dropout(li, io)) {
         float* pbuf[2] = {part, part_b};
         for (int l = li.L - 1; l >= 0; --l) {
@@ -545,7 +597,7 @@ size_t dropout_scratch_floats(const dp_encoder_cfg& c) {
 
 struct Scratch {
     float* xm[2];
-    float *Pj, *Uj, *part, *part_b, *logits;
+    float *Pj, *Uj, *part, *part_b, *logits, *lvl_part;
     unsigned short* vs;      // 3-plane bf16 split of the current V operand (level 0, packed adjacency)
 };
 size_t vs_elems(const dp_encoder_cfg& c) {
@@ -597,6 +649,7 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
     s.part = q.alloc<float>(maxPart);
     s.part_b = q.alloc<float>(maxPart);
     s.logits = q.alloc<float>(maxLog > 0 ? maxLog : 1);
+    s.lvl_part = q.alloc<float>(level_part_floats(c));
     s.vs = q.alloc<unsigned short>(vs_elems(c));
     const size_t dsf = dropout_scratch_floats(c);
     s.xm[0] = dsf ? q.alloc<float>(dsf) : nullptr;
@@ -630,9 +683,16 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
     int featoff = 0;
     const bool fused_head = head_usable(c);
     HeadArgs head = head_args(c, sv, params, ypred);
+    // grid-barrier tickets of a whole-level kernel: cleared in stream order by the softmax launch of the level below
+    // (together with its split-K tickets); a small level 0 has no such launch in front of it and clears its own
+    int* level_bar = nullptr;
     for (int j = 0; j <= P; ++j) {
         const LevelInfo li = level_info(c, j);
         const LevelSave& lv = sv.lv[j];
+        if (j == 0 && li.G == 1 && li.n <= 64) {
+            level_bar = q.alloc<int>(64);
+            if (q.ok()) zero_small(q, level_bar, 64 * sizeof(int));
+        }
         LevelIO io{};
         io.x0e = j == 0 ? x : sv.lv[j - 1].Xn;
         io.x0a = j == 0 ? assign_x : sv.lv[j - 1].Xn;
@@ -641,7 +701,9 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
         io.xm[0] = sc.xm[0];
         io.xm[1] = sc.xm[1];
         io.pack = (j == 0 && pack_in_level) ? &pack : nullptr;
-        level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part, sc.part_b, j == 0 ? pkp : nullptr, sc.vs);
+        level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part, sc.part_b, j == 0 ? pkp : nullptr, sc.vs,
+                      sc.lvl_part, level_bar);
+        level_bar = nullptr;
         const int* nn_j = (j == 0) ? num_nodes : nullptr;
         if (c.readout == 0) {
             const int rw = readout_width(c, li);
@@ -674,10 +736,13 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
             // here made X' and A' vary in the last bit from run to run, enough to flip a near-tied max-readout
             // winner downstream and route its gradient to another row; the softmax launch zero-fills the tickets)
             const size_t cnt_ints = ksn > 1 ? gemm_fix_counters(B, K, li.D) + gemm_fix_counters(B, K, K) : 0;
-            int* fix_cnt = ksn > 1 ? q.alloc<int>((cnt_ints + 63) & ~size_t(63)) : nullptr;
+            const size_t cnt_pad = (cnt_ints + 63) & ~size_t(63);
+            int* sync_blk = q.alloc<int>(64 + cnt_pad);          // [level_bar of level j + 1 | split-K tickets]
+            int* fix_cnt = ksn > 1 && sync_blk ? sync_blk + 64 : nullptr;
             float* fix_part = ksn > 1 ? q.alloc<float>((size_t)B * ksn * K * (li.D + K)) : nullptr;
             softmax_mask_fwd(q, sc.logits, K, lv.S, K, nn_j, B, n, K, j == 0 ? assign_out : nullptr,
-                             s_split ? sc.vs : nullptr, fix_cnt, ((cnt_ints + 63) & ~size_t(63)) * sizeof(int));
+                             s_split ? sc.vs : nullptr, sync_blk, (64 + cnt_pad) * sizeof(int));
+            level_bar = sync_blk;
             aggregate(q, io.adj, lv.S, K, lv.T, K, B, n, K, true, 0.f, j == 0 ? pkp : nullptr, sc.vs, s_split);
             {
                 // both pooled outputs in ONE launch (X' does not need T, but a launch of its own costs more than
@@ -740,6 +805,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     float* Gj = q.alloc<float>(maxPU);
     float* part = q.alloc<float>(maxPart);
     float* part_b = q.alloc<float>(maxPart);
+    float* lvl_part = q.alloc<float>(level_part_floats(c));
     unsigned short* vs = q.alloc<unsigned short>(vs_elems(c));
     float* dS = q.alloc<float>(maxSK ? maxSK : 1);
     float* dlog = q.alloc<float>(maxSK ? maxSK : 1);
@@ -886,7 +952,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
             }
         }
         level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, KS, Pj, dUj, Gj, part, part_b,
-                       j == 0 ? pkp : nullptr, vs, dxm);
+                       j == 0 ? pkp : nullptr, vs, dxm, lvl_part, bz.bar + 64 * j);
     }
     reduce_slabs(q, slabs, slab_stride, B * KS, grads, c.n_graph_params, 0);
     return q.err;

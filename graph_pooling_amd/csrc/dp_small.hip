@@ -408,6 +408,417 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
     SM_STAMP(1, 7);
 }
 
+// =========================================================================================================
+// Whole-level kernels: ALL layers of a pooled level's GCN stack in one launch per direction.
+//
+// One workgroup per graph keeps the level's adjacency, every layer's weights and the running activations in LDS
+// across the layers; the only thing that crosses workgroups is apply_bn (encoders.py:1048-1052: statistics per node
+// index over batch x features), which needs every graph's row partials between two layers.  They travel through
+// global memory behind a GRID BARRIER: B <= (CUs / 2) workgroups of 1024 threads are co-resident by construction
+// (one per CU), so a ticket barrier cannot deadlock — and it is bounded anyway: a workgroup that waits longer than
+// ~1 s gives up, raises the error word next to the ticket and poisons its statistics with NaN, so a broken
+// co-residency assumption shows up as NaN outputs, never as a hung GPU.
+//
+// Memory model (this is the part that is easy to get wrong on a multi-XCD part: each XCD has its own L2, and plain
+// stores / loads of different XCDs are not coherent inside one kernel): the exchanged partials are written with
+// agent-scope atomic stores (write-through to the device's coherence point) and read with agent-scope atomic loads
+// (served past the XCD-local L2).  The ticket is an agent-scope RELEASE fetch-add issued after a workgroup barrier,
+// the spin an agent-scope ACQUIRE load: a proper release/acquire pair, so the ordering does not rest on ISA
+// behaviour.  Its cost was measured at the DD shape: ~1.5 us per barrier.
+// The tickets are zeroed in stream order by an earlier launch of the same sequence (never by a memset node).
+constexpr int SM_SPIN_LIMIT = 1 << 20;
+
+__device__ inline void sm_st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline float sm_ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// returns false when the wait gave up.  `flag` is an LDS word.
+__device__ inline bool sm_grid_barrier(int* bar, int target, int* flag) {
+    __syncthreads();                        // every thread's exchange stores are issued and acknowledged
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int it = 0, ok = 1;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++it > SM_SPIN_LIMIT) {
+                ok = 0;
+                __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+struct SmallLevelFwdArgs {
+    const float* adj;      // [B, n, n]
+    const float* x0;       // [B, n, dims[0]] (ld = ldx0)
+    int ldx0;
+    const float* params;
+    long w_off[DP_MAX_LAYERS], b_off[DP_MAX_LAYERS];
+    int dims[DP_MAX_LAYERS + 1];
+    int L;
+    float* Y[DP_MAX_LAYERS];       // non-last layers: normalised pre-ReLU output [B, n, dims[l+1]] (ld = ldY[l])
+    int ldY[DP_MAX_LAYERS];
+    float* invn[DP_MAX_LAYERS];    // [B, n]
+    float* stats[DP_MAX_LAYERS];   // non-last layers with BN: [n, 2] (mu, rstd)
+    float* Ze;                     // concat buffer [B, n, ldz]; layer l's slice starts at column coff[l]
+    int ldz;
+    int coff[DP_MAX_LAYERS];
+    float* part;                   // exchange: [L-1][B][n][2] (row mean, row M2) of relu(y)
+    int* bar;                      // bar[0] ticket (zero at launch), bar[1] error word
+    int B, n, add_self, bn;
+    int dmax, omax, wtot, btot;    // max layer input width, max output width, total weight / bias floats
+    SmDiv qd0;
+};
+
+__global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int bar_ok;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.n, L = a.L;
+    float* A = lds;                        // [n][n]
+    float* X = A + n * n;                  // [n][dmax]  current layer input
+    float* P = X + n * a.dmax;             // [n][omax]
+    float* U = P + n * a.omax;             // [n][omax]  pre-normalisation, then y
+    float* mu = U + n * a.omax;            // [n]
+    float* rs = mu + n;                    // [n]
+    float* WL = rs + n;                    // all layers' weights, back to back
+    float* BI = WL + a.wtot;               // all layers' biases (zeros where a layer has none)
+    float* PP = BI + a.btot;               // [B][n][2] partials of the layer being normalised
+    const int tl = tid & 15, team = tid >> 4;
+    const int NT = blockDim.x, NTEAMS = blockDim.x >> 4;
+
+    // ---- one burst: adjacency, level input, every layer's weights and biases
+    sm_dma(A, n * n, [&](int e) { return a.adj + (long)b * n * n + e; });
+    {
+        const int d0 = a.dims[0];
+        sm_dma(X, n * d0, [&](int e) { return a.x0 + ((long)b * n + a.qd0.quot(e)) * a.ldx0 + a.qd0.rem(e); });
+    }
+    {
+        int wo = 0, bo = 0;
+        for (int l = 0; l < L; ++l) {
+            const int din = a.dims[l], dout = a.dims[l + 1];
+            const float* w = a.params + a.w_off[l];
+            sm_dma(WL + wo, din * dout, [&](int e) { return w + e; });
+            if (a.b_off[l] >= 0) {
+                const float* bs = a.params + a.b_off[l];
+                sm_dma(BI + bo, dout, [&](int e) { return bs + e; });
+            } else {
+                for (int i = tid; i < dout; i += NT) BI[bo + i] = 0.f;
+            }
+            wo += din * dout;
+            bo += dout;
+        }
+    }
+    __syncthreads();
+
+    int wo = 0, bo = 0;
+    for (int l = 0; l < L; ++l) {
+        const int din = a.dims[l], dout = a.dims[l + 1];
+        const bool last = l == L - 1;
+        const float* W = WL + wo;
+        const float* BL = BI + bo;
+        // P = X W
+        lds_mma<false, false>(X, din, W, dout, n, dout, din, [&](int r, int c, float v) { P[r * dout + c] = v; });
+        __syncthreads();
+        // U = A P (+ P) + bias
+        lds_mma<false, false>(A, n, P, dout, n, dout, n, [&](int r, int c, float v) {
+            if (a.add_self) v += P[r * dout + c];
+            U[r * dout + c] = v + BL[c];
+        });
+        __syncthreads();
+        // l2-normalise rows -> y (kept in U), saved output, BN partials of relu(y)
+        const bool stats = !last && a.bn;
+        float* part_l = a.part + (long)l * a.B * n * 2;
+        for (int r = team; r < n; r += NTEAMS) {
+            const long row = (long)b * n + r;
+            float ss = 0.f;
+            for (int c = tl; c < dout; c += 16) ss += U[r * dout + c] * U[r * dout + c];
+            ss = sm_team_sum(ss);
+            const float inv = 1.f / fmaxf(sqrtf(ss), SM_L2_EPS);
+            float s1 = 0.f;
+            float* yg = last ? a.Ze + row * a.ldz + a.coff[l] : a.Y[l] + row * a.ldY[l];
+            for (int c = tl; c < dout; c += 16) {
+                const float v = U[r * dout + c] * inv;
+                U[r * dout + c] = v;
+                yg[c] = v;
+                s1 += fmaxf(v, 0.f);
+            }
+            if (tl == 0) a.invn[l][row] = inv;
+            if (stats) {
+                s1 = sm_team_sum(s1);
+                const float mean = s1 / (float)dout;
+                float m2 = 0.f;
+                for (int c = tl; c < dout; c += 16) {
+                    const float v = fmaxf(U[r * dout + c], 0.f) - mean;
+                    m2 += v * v;
+                }
+                m2 = sm_team_sum(m2);
+                if (tl == 0) {
+                    sm_st_agent(part_l + row * 2, mean);
+                    sm_st_agent(part_l + row * 2 + 1, m2);
+                }
+            }
+        }
+        if (last) break;
+        if (stats) {
+            // every graph's partials of this layer, then the statistics per node index (Chan combine)
+            const bool ok = sm_grid_barrier(a.bar, (l + 1) * a.B, &bar_ok);
+            for (int e = tid; e < a.B * n * 2; e += NT) PP[e] = sm_ld_agent(part_l + e);
+            __syncthreads();
+            for (int r = tid; r < n; r += NT) {
+                float sm = 0.f;
+#pragma unroll 4
+                for (int bb = 0; bb < a.B; ++bb) sm += PP[(bb * n + r) * 2];
+                float m = sm / (float)a.B;
+                float s2 = 0.f;
+#pragma unroll 4
+                for (int bb = 0; bb < a.B; ++bb) {
+                    const float d = PP[(bb * n + r) * 2] - m;
+                    s2 += PP[(bb * n + r) * 2 + 1] + (float)dout * d * d;
+                }
+                float rstd = 1.0f / sqrtf(s2 / ((float)a.B * (float)dout) + SM_BN_EPS);
+                if (!ok) m = rstd = __builtin_nanf("");        // a barrier that gave up must not go unnoticed
+                if (b == 0) {
+                    a.stats[l][r * 2] = m;
+                    a.stats[l][r * 2 + 1] = rstd;
+                }
+                mu[r] = m;
+                rs[r] = rstd;
+            }
+        } else {
+            for (int r = tid; r < n; r += NT) {
+                mu[r] = 0.f;
+                rs[r] = 1.f;
+            }
+        }
+        __syncthreads();
+        // next layer's input: x = (relu(y) - mu) * rstd, also this layer's slice of the concat buffer
+        for (int r = team; r < n; r += NTEAMS)
+            for (int k = tl; k < dout; k += 16) {
+                const float v = (fmaxf(U[r * dout + k], 0.f) - mu[r]) * rs[r];
+                X[r * dout + k] = v;
+                a.Ze[((long)b * n + r) * a.ldz + a.coff[l] + k] = v;
+            }
+        __syncthreads();
+        wo += din * dout;
+        bo += dout;
+    }
+}
+
+struct SmallLevelBwdArgs {
+    const float* adj;      // [B, n, n]
+    const float* x0;       // level input [B, n, dims[0]] (ld = ldx0)
+    int ldx0;
+    const float* params;
+    long w_off[DP_MAX_LAYERS], b_off[DP_MAX_LAYERS];
+    int dims[DP_MAX_LAYERS + 1];
+    int L;
+    const float* Y[DP_MAX_LAYERS];     // non-last layers: normalised pre-ReLU output (ld = ldY[l])
+    int ldY[DP_MAX_LAYERS];
+    const float* invn[DP_MAX_LAYERS];
+    const float* stats[DP_MAX_LAYERS];
+    const float* Ze;                   // concat buffer: BN outputs of the non-last layers, y of the last
+    int ldz;
+    int coff[DP_MAX_LAYERS];
+    const float* dZe;                  // gradient of the concat buffer [B, n, ldz] (readout scatter etc.), read only
+    float* dX0;                        // [B, n, dims[0]] out (overwritten), or null
+    float* dadj;                       // [B, n, n] out (overwritten), or null
+    float* slabs;                      // parameter-gradient slab of graph 0 (graphs slab_stride apart)
+    long slab_stride;
+    float* part;                       // exchange: [L-1][B][n][2] (sum dx, sum dx * xhat)
+    int* bar;
+    int B, n, add_self, bn;
+    int omax, wtot, D;                 // max layer output width, total weight floats, concat width
+    SmDiv qd0, qD;
+    SmDiv qdout[DP_MAX_LAYERS];
+};
+
+__global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int bar_ok;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.n, L = a.L, D = a.D, d0 = a.dims[0];
+    float* A = lds;                        // [n][n]
+    float* DA = A + n * n;                 // [n][n] running dA (only when wanted)
+    float* X0 = DA + (a.dadj ? n * n : 0); // [n][d0]
+    float* ZE = X0 + n * d0;               // [n][D]  concat buffer slices (xhat_l for l < L-1, y_{L-1})
+    float* DZ = ZE + n * D;                // [n][D]  gradient w.r.t. the concat buffer, running totals
+    float* YS = DZ + n * D;                // [L-1][n][omax] normalised pre-ReLU outputs of the non-last layers
+    float* WL = YS + (L - 1) * n * a.omax; // all weights
+    float* IV = WL + a.wtot;               // [L][n]
+    float* RS = IV + L * n;                // [L][n]
+    float* dU = RS + L * n;                // [n][omax]
+    float* G = dU + n * a.omax;            // [n][omax]
+    float* P = G + n * a.omax;             // [n][omax]
+    float* M0 = P + n * a.omax;            // [n]
+    float* M1 = M0 + n;                    // [n]
+    float* DB = M1 + n;                    // [omax]
+    float* PP = DB + a.omax;               // [B][n][2]
+    const int tl = tid & 15, team = tid >> 4;
+    const int NT = blockDim.x, NTEAMS = blockDim.x >> 4;
+
+    // ---- one burst
+    sm_dma(A, n * n, [&](int e) { return a.adj + (long)b * n * n + e; });
+    sm_dma(X0, n * d0, [&](int e) { return a.x0 + ((long)b * n + a.qd0.quot(e)) * a.ldx0 + a.qd0.rem(e); });
+    sm_dma(ZE, n * D, [&](int e) { return a.Ze + ((long)b * n + a.qD.quot(e)) * a.ldz + a.qD.rem(e); });
+    sm_dma(DZ, n * D, [&](int e) { return a.dZe + ((long)b * n + a.qD.quot(e)) * a.ldz + a.qD.rem(e); });
+    {
+        int wo = 0;
+        for (int l = 0; l < L; ++l) {
+            const int din = a.dims[l], dout = a.dims[l + 1];
+            const float* w = a.params + a.w_off[l];
+            sm_dma(WL + wo, din * dout, [&](int e) { return w + e; });
+            wo += din * dout;
+            const float* iv = a.invn[l] + (long)b * n;
+            sm_dma(IV + l * n, n, [&](int e) { return iv + e; });
+            if (l < L - 1) {
+                const float* y = a.Y[l];
+                const int ldy = a.ldY[l];
+                const SmDiv q = a.qdout[l];
+                sm_dma(YS + l * n * a.omax, n * dout, [&](int e) { return y + ((long)b * n + q.quot(e)) * ldy + q.rem(e); });
+                if (a.bn) {
+                    const float* st = a.stats[l];
+                    sm_dma(RS + l * n, n, [&](int e) { return st + e * 2 + 1; });
+                }
+            }
+        }
+    }
+    if (a.dadj)
+        for (int i = tid; i < n * n; i += NT) DA[i] = 0.f;
+    __syncthreads();
+
+    int wo_end = a.wtot;
+    int nbar = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        const int din = a.dims[l], dout = a.dims[l + 1];
+        const bool last = l == L - 1;
+        const bool has_bn = !last && a.bn;
+        const bool has_relu = !last;
+        wo_end -= din * dout;
+        const float* W = WL + wo_end;
+        const float* Xl = l == 0 ? X0 : ZE + a.coff[l - 1];     // layer input (row stride ldx)
+        const int ldx = l == 0 ? d0 : D;
+        const float* Yl = last ? ZE + a.coff[l] : YS + l * n * a.omax;   // normalised output
+        const int ldy = last ? D : dout;
+        float* dx = DZ + a.coff[l];                               // gradient w.r.t. this layer's output (ld D)
+        for (int i = tid; i < dout; i += NT) DB[i] = 0.f;
+        if (has_bn) {
+            // BN backward needs, per node index, the sums over ALL graphs of (dx, dx * xhat)
+            float* part_l = a.part + (long)l * a.B * n * 2;
+            const float* xh = ZE + a.coff[l];
+            for (int r = team; r < n; r += NTEAMS) {
+                float s0 = 0.f, s1 = 0.f;
+                for (int c = tl; c < dout; c += 16) {
+                    const float d = dx[r * D + c];
+                    s0 += d;
+                    s1 += d * xh[r * D + c];
+                }
+                s0 = sm_team_sum(s0);
+                s1 = sm_team_sum(s1);
+                if (tl == 0) {
+                    sm_st_agent(part_l + ((long)b * n + r) * 2, s0);
+                    sm_st_agent(part_l + ((long)b * n + r) * 2 + 1, s1);
+                }
+            }
+            ++nbar;
+            const bool ok = sm_grid_barrier(a.bar, nbar * a.B, &bar_ok);
+            for (int e = tid; e < a.B * n * 2; e += NT) PP[e] = sm_ld_agent(part_l + e);
+            __syncthreads();
+            for (int r = tid; r < n; r += NT) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+                for (int bb = 0; bb < a.B; ++bb) {
+                    s0 += PP[(bb * n + r) * 2];
+                    s1 += PP[(bb * n + r) * 2 + 1];
+                }
+                const float cnt = (float)a.B * (float)dout;
+                M0[r] = ok ? s0 / cnt : __builtin_nanf("");
+                M1[r] = s1 / cnt;
+            }
+        }
+        __syncthreads();
+        // ---- dU = normalise^T relu^T bn^T dx, one team per row (uniform trip count: the bias sums reduce across
+        // the four row teams of a wave)
+        float* dbb = a.b_off[l] >= 0 ? a.slabs + (long)b * a.slab_stride + a.b_off[l] : nullptr;
+        for (int r0 = 0; r0 < n; r0 += NTEAMS) {
+            const int r = min(r0 + team, n - 1);
+            const bool valid = r0 + team < n;
+            const float rstd = has_bn ? RS[l * n + r] : 1.f;
+            const float m0 = has_bn ? M0[r] : 0.f, m1 = has_bn ? M1[r] : 0.f;
+            const float inv = IV[l * n + r];
+            const bool project = inv < 1.0f / SM_L2_EPS;
+            float dot = 0.f;
+            float dv[4];                                   // dout <= 64 on this path (see small_level_fused_ok)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = tl + 16 * k;
+                float d = 0.f;
+                if (c < dout) {
+                    d = dx[r * D + c];
+                    const float yy = Yl[r * ldy + c];
+                    if (has_bn) d = rstd * (d - m0 - ZE[r * D + a.coff[l] + c] * m1);
+                    if (has_relu) d = yy > 0.f ? d : 0.f;
+                    dot += d * yy;
+                }
+                dv[k] = d;
+            }
+            dot = sm_team_sum(dot);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = tl + 16 * k;
+                float v = 0.f;
+                if (c < dout && valid) {
+                    v = project ? inv * (dv[k] - Yl[r * ldy + c] * dot) : inv * dv[k];
+                    dU[r * dout + c] = v;
+                }
+                if (dbb && 16 * k < dout) {
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if ((tid & 63) < 16 && c < dout) atomicAdd(&DB[c], v);
+                }
+            }
+        }
+        __syncthreads();
+        if (dbb)
+            for (int c = tid; c < dout; c += NT) dbb[c] = DB[c];
+        // G = A^T dU (+ dU);  P = X W (for dA)
+        lds_mma<true, false>(A, n, dU, dout, n, dout, n, [&](int m, int c, float v) {
+            G[m * dout + c] = a.add_self ? v + dU[m * dout + c] : v;
+        });
+        if (a.dadj)
+            lds_mma<false, false>(Xl, ldx, W, dout, n, dout, din, [&](int m, int c, float v) { P[m * dout + c] = v; },
+                                  ((n + 15) / 16) * ((dout + 15) / 16));
+        __syncthreads();
+        // dW = X^T G -> this graph's slab
+        {
+            float* dWb = a.slabs + (long)b * a.slab_stride + a.w_off[l];
+            lds_mma<true, false>(Xl, ldx, G, dout, din, dout, n, [&](int k, int c, float v) { dWb[k * dout + c] = v; });
+        }
+        // gradient w.r.t. the layer input: G W^T
+        if (l > 0) {
+            float* dxin = DZ + a.coff[l - 1];
+            lds_mma<false, true>(G, dout, W, dout, n, din, dout, [&](int r, int k, float v) { dxin[r * D + k] += v; },
+                                 1);
+        } else if (a.dX0) {
+            lds_mma<false, true>(G, dout, W, dout, n, din, dout, [&](int r, int k, float v) {
+                a.dX0[((long)b * n + r) * d0 + k] = v;
+            }, 1);
+        }
+        // dA += dU P^T
+        if (a.dadj)
+            lds_mma<false, true>(dU, dout, P, dout, n, n, dout, [&](int r, int m, float v) { DA[r * n + m] += v; }, 2);
+        __syncthreads();
+    }
+    if (a.dadj)
+        for (int i = tid; i < n * n; i += NT) a.dadj[(long)b * n * n + i] = DA[i];
+}
+
 size_t small_lds_floats_fwd(int B, int n, int din, int dout) {
     return (size_t)n * n + (size_t)n * din + (size_t)din * dout + 2 * (size_t)n * dout + 2 * n + dout +
            (size_t)B * n * 2 + 16;
@@ -458,6 +869,106 @@ void small_gcn_bwd(Seq& q, const float* adj, const float* xin, int ldxin, const 
     hipLaunchKernelGGL(k_small_gcn_bwd, dim3(B), dim3(1024), small_lds_floats_bwd(B, n, din, dout) * sizeof(float),
                        q.stream, a);
     q.check_launch("small_gcn_bwd");
+}
+
+
+// ---- whole-level launchers
+static size_t small_level_lds_fwd(int B, int n, const int* dims, int L) {
+    int dmax = 0, omax = 0, wtot = 0, btot = 0;
+    for (int l = 0; l < L; ++l) {
+        dmax = dims[l] > dmax ? dims[l] : dmax;
+        omax = dims[l + 1] > omax ? dims[l + 1] : omax;
+        wtot += dims[l] * dims[l + 1];
+        btot += dims[l + 1];
+    }
+    return (size_t)n * n + (size_t)n * dmax + 2 * (size_t)n * omax + 2 * n + wtot + btot + (size_t)B * n * 2 + 16;
+}
+static size_t small_level_lds_bwd(int B, int n, const int* dims, int L, bool dadj) {
+    int omax = 0, wtot = 0, D = 0;
+    for (int l = 0; l < L; ++l) {
+        omax = dims[l + 1] > omax ? dims[l + 1] : omax;
+        wtot += dims[l] * dims[l + 1];
+        D += dims[l + 1];
+    }
+    return (size_t)n * n * (dadj ? 2 : 1) + (size_t)n * dims[0] + 2 * (size_t)n * D + (size_t)(L - 1) * n * omax + wtot +
+           2 * (size_t)L * n + 3 * (size_t)n * omax + 2 * n + omax + (size_t)B * n * 2 + 16;
+}
+static int device_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        hipDeviceProp_t prop;
+        v = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : -1;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v > 0 ? v : 0;
+}
+// All layers of the level in one launch: shapes the kernels take AND a batch whose workgroups are certainly
+// co-resident (one 1024-thread workgroup per CU; half the CUs is the margin for a partitioned or shared device).
+bool small_level_fused_ok(int B, int n, const int* dims, int L, bool dadj) {
+    if (knobs().no_level_fusion || L < 2 || L > DP_MAX_LAYERS || n > 64) return false;
+    for (int l = 0; l <= L; ++l)
+        if (dims[l] > 256 || (l > 0 && dims[l] > 64)) return false;
+    if (small_level_lds_fwd(B, n, dims, L) * sizeof(float) > 150 * 1024) return false;
+    if (small_level_lds_bwd(B, n, dims, L, dadj) * sizeof(float) > 150 * 1024) return false;
+    const int cus = device_cus();
+    return cus > 0 && B <= cus / 2;
+}
+size_t small_level_part_floats(int B, int n, int L) { return (size_t)(L > 1 ? L - 1 : 1) * B * n * 2; }
+
+void small_level_fwd(Seq& q, const SmallLevelIO& io, int B, int n, const int* dims, int L, int add_self, int bn) {
+    if (!q.ok()) return;
+    static DynLdsOnce attr;
+    ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_small_level_fwd), 159 * 1024, "k_small_level_fwd");
+    if (!q.ok()) return;
+    SmallLevelFwdArgs a{};
+    a.adj = io.adj; a.x0 = io.x0; a.ldx0 = io.ldx0; a.params = io.params; a.L = L;
+    a.Ze = io.Ze; a.ldz = io.ldz; a.part = io.part; a.bar = io.bar;
+    a.B = B; a.n = n; a.add_self = add_self; a.bn = bn;
+    for (int l = 0; l <= L; ++l) a.dims[l] = dims[l];
+    for (int l = 0; l < L; ++l) {
+        a.w_off[l] = io.w_off[l]; a.b_off[l] = io.b_off[l];
+        a.Y[l] = io.Y[l]; a.ldY[l] = io.ldY[l]; a.invn[l] = io.invn[l]; a.stats[l] = io.stats[l];
+        a.coff[l] = io.coff[l];
+        a.dmax = dims[l] > a.dmax ? dims[l] : a.dmax;
+        a.omax = dims[l + 1] > a.omax ? dims[l + 1] : a.omax;
+        a.wtot += dims[l] * dims[l + 1];
+        a.btot += dims[l + 1];
+    }
+    a.qd0 = sm_div(dims[0]);
+    hipLaunchKernelGGL(k_small_level_fwd, dim3(B), dim3(1024), small_level_lds_fwd(B, n, dims, L) * sizeof(float),
+                       q.stream, a);
+    q.check_launch("small_level_fwd");
+}
+
+void small_level_bwd(Seq& q, const SmallLevelIO& io, const float* dZe, float* dX0, float* dadj, float* slabs,
+                     long slab_stride, int B, int n, const int* dims, int L, int add_self, int bn) {
+    if (!q.ok()) return;
+    static DynLdsOnce attr;
+    ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_small_level_bwd), 159 * 1024, "k_small_level_bwd");
+    if (!q.ok()) return;
+    SmallLevelBwdArgs a{};
+    a.adj = io.adj; a.x0 = io.x0; a.ldx0 = io.ldx0; a.params = io.params; a.L = L;
+    a.Ze = io.Ze; a.ldz = io.ldz; a.part = io.part; a.bar = io.bar;
+    a.dZe = dZe; a.dX0 = dX0; a.dadj = dadj; a.slabs = slabs; a.slab_stride = slab_stride;
+    a.B = B; a.n = n; a.add_self = add_self; a.bn = bn;
+    for (int l = 0; l <= L; ++l) a.dims[l] = dims[l];
+    for (int l = 0; l < L; ++l) {
+        a.w_off[l] = io.w_off[l]; a.b_off[l] = io.b_off[l];
+        a.Y[l] = io.Y[l]; a.ldY[l] = io.ldY[l]; a.invn[l] = io.invn[l]; a.stats[l] = io.stats[l];
+        a.coff[l] = io.coff[l];
+        a.omax = dims[l + 1] > a.omax ? dims[l + 1] : a.omax;
+        a.wtot += dims[l] * dims[l + 1];
+        a.D += dims[l + 1];
+        a.qdout[l] = sm_div(dims[l + 1]);
+    }
+    a.qd0 = sm_div(dims[0]);
+    a.qD = sm_div(a.D);
+    hipLaunchKernelGGL(k_small_level_bwd, dim3(B), dim3(1024),
+                       small_level_lds_bwd(B, n, dims, L, dadj != nullptr) * sizeof(float), q.stream, a);
+    q.check_launch("small_level_bwd");
 }
 
 #ifdef DP_STAMP

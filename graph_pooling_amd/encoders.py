@@ -125,7 +125,8 @@ class _EncoderFn(torch.autograd.Function):
     """One FFI call per pass: dp_encoder_forward / dp_encoder_backward."""
 
     @staticmethod
-    def forward(ctx, owner, x, adj, assign_x, num_nodes, drop, *params):
+    def forward(ctx, owner, x, adj, assign_x, num_nodes, drop, needs_grad, *params):
+        # needs_grad is decided by the caller: grad mode is always off inside Function.forward
         lib = _lib.load()
         plan = owner._plan(x.shape[0], x.shape[1], x.device)
         B = plan.cfg.B
@@ -133,7 +134,6 @@ class _EncoderFn(torch.autograd.Function):
         assign = None
         if plan.cfg.num_pooling > 0:
             assign = torch.empty(B, plan.cfg.N, plan.cfg.n_nodes[1], device=x.device, dtype=torch.float32)
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         save = torch.empty(plan.save_bytes, device=x.device, dtype=torch.uint8) if needs_grad else plan.eval_save()
         stream = _lib.current_stream()
         _lib.check(lib.dp_encoder_forward(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(), adj.data_ptr(),
@@ -172,7 +172,7 @@ class _EncoderFn(torch.autograd.Function):
                                            plan.save_bytes, plan.workspace.data_ptr(), plan.ws_bytes, prezeroed,
                                            _lib.current_stream()), "dp_encoder_backward")
         owner._last_flat_grad = grads
-        out = [None, None, None, None, None, None]
+        out = [None, None, None, None, None, None, None]
         for (off, numel, shape) in owner._flat_index:
             out.append(grads[off:off + numel].view(shape))
         return tuple(out)
@@ -431,7 +431,8 @@ class GcnEncoderGraph(nn.Module):
         drop = getattr(self, "_forced_dropout_mask", None)       # tests inject the oracle's masks here
         if drop is None:
             drop = self._draw_dropout(self._plan(x.shape[0], x.shape[1], x.device), x.device)
-        return _EncoderFn.apply(self, x, adj, assign_x, nn_dev, drop, *self._flat_params)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params)
+        return _EncoderFn.apply(self, x, adj, assign_x, nn_dev, drop, needs_grad, *self._flat_params)
 
     # -- reference surface
     def construct_mask(self, max_nodes, batch_num_nodes):

@@ -352,6 +352,38 @@ def test_eval_mode_and_no_grad_match_train_forward():
     assert torch.equal(labels, y1.argmax(dim=1))
 
 
+def test_two_forwards_before_their_backwards():
+    """Each training forward keeps its own activations, and only the latest forward may hand its pre-cleared
+    accumulators to a backward pass (DP_MODE_TRAIN / prezeroed): fwd(a), fwd(b), bwd(a), bwd(b) — and a second backward
+    through a retained graph — must give the gradients of separate steps."""
+    B, N, F_, H, Cc = 5, 160, 6, 10, 3
+    xa, adja, nna, la = O.make_batch(B, N, F_, n_min=20, p=0.05, seed=11, n_classes=Cc)
+    xb, adjb, nnb, lb = O.make_batch(B, N, F_, n_min=20, p=0.05, seed=12, n_classes=Cc)
+    model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, 3, H, assign_ratio=0.2, linkpred=True).cuda()
+
+    def grads_of(loss, **kw):
+        model.zero_grad(set_to_none=True)
+        loss.backward(**kw)
+        return {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    def run(x, adj, nn_, label):
+        xd, ad = x.cuda(), adj.cuda()
+        y = model(xd, ad, nn_, assign_x=xd)
+        return model.loss(y, label.cuda(), ad, nn_)
+    ga = grads_of(run(xa, adja, nna, la))
+    gb = grads_of(run(xb, adjb, nnb, lb))
+    loss_a = run(xa, adja, nna, la)
+    loss_b = run(xb, adjb, nnb, lb)
+    ga2 = grads_of(loss_a, retain_graph=True)
+    gb2 = grads_of(loss_b)
+    ga3 = grads_of(loss_a)                         # second backward through the retained graph
+    for k in ga:
+        exact = not k.endswith("bias")             # bias sums are float atomics: last-place differences
+        close(ga2[k], ga[k], 0 if exact else 1e-5, 0 if exact else 1e-7)
+        close(gb2[k], gb[k], 0 if exact else 1e-5, 0 if exact else 1e-7)
+        close(ga3[k], ga[k], 0 if exact else 1e-5, 0 if exact else 1e-7)
+
+
 def test_linearity_of_pooling_at_full_size():
     """Size-independent property at the DD shape: with S fixed, X' = S^T Z is linear in Z and
     A' = S^T A S is linear in A (checked through dp_pool_fwd on the full B=20, N=500 batch)."""
