@@ -105,6 +105,65 @@ __device__ inline void lds_mma(const float* A, int lda, const float* B, int ldb,
     }
 }
 
+
+// Same contract as lds_mma, shaped for instruction ISSUE: with 16 waves on four SIMDs (only the waves that own a
+// tile are busy) a product is bound by the ~200 vector instructions of address arithmetic per tile — clamp, multiply,
+// shift-add and a select per fragment element, ~15 cycles each in dependent chains — not by LDS or MFMA time
+// (in-kernel stamps: 3.0k cycles for ONE 16x16 tile with K = 50).  Here a fragment address is a running pointer: one
+// add per operand and k-step; full k-steps carry no clamp and no select (rows / columns past M / N are clamped once
+// per tile: their products land in output elements nobody stores); only the one partial k-step at the end of K is
+// masked.  Batches of four k-steps have their eight LDS reads in flight before the first MFMA; two accumulators.
+template <bool TA, bool TB, typename Store>
+__device__ inline void lds_mma2(const float* A, int lda, const float* B, int ldb, int M, int N, int K, Store store,
+                                int wave_shift = 0) {
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = ((threadIdx.x >> 6) + nwaves - wave_shift % nwaves) % nwaves;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int tm = (M + 15) / 16, tn = (N + 15) / 16;
+    const int sa4 = 4 * (TA ? lda : 1), sb4 = 4 * (TB ? 1 : ldb);     // element stride of one k-step
+    int tr = wave / tn, tc = wave - tr * tn;                           // (tile row, tile column), advanced by nwaves
+    const int dr = nwaves / tn, dc = nwaves - dr * tn;
+    for (; tr < tm; ) {
+        const int i = tr * 16 + l15, j = tc * 16 + l15;
+        const float* ap = (TA ? A + min(i, M - 1) : A + min(i, M - 1) * lda) + kq * (sa4 >> 2);
+        const float* bp = (TB ? B + min(j, N - 1) * ldb : B + min(j, N - 1)) + kq * (sb4 >> 2);
+        sm_f32x4 acc0 = (sm_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        int k = 0;
+        for (; k + 16 <= K; k += 16) {
+            const float a0 = ap[0], a1 = ap[sa4], a2 = ap[2 * sa4], a3 = ap[3 * sa4];
+            const float b0 = bp[0], b1 = bp[sb4], b2 = bp[2 * sb4], b3 = bp[3 * sb4];
+            ap += 4 * sa4;
+            bp += 4 * sb4;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc1, 0, 0, 0);
+        }
+        for (; k + 4 <= K; k += 4) {
+            const float a0 = ap[0], b0 = bp[0];
+            ap += sa4;
+            bp += sb4;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+        }
+        if (k < K) {                        // partial k-step: lanes with k >= K contribute 0 (the load is discarded)
+            const bool kin = k + kq < K;
+            const float a0 = ap[0], b0 = bp[0];
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kin ? a0 : 0.f, kin ? b0 : 0.f, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = tr * 16 + kq * 4 + r;
+            if (row < M && j < N) store(row, j, acc0[r] + acc1[r]);
+        }
+        tr += dr;
+        tc += dc;
+        if (tc >= tn) {
+            tc -= tn;
+            ++tr;
+        }
+    }
+}
+
 struct SmallFwdArgs {
     const float* adj;      // [B, n, n]
     const float* x0;       // layer 0: raw input [B, n, din] (ld = ldx0); else null
@@ -426,7 +485,15 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
 // the spin an agent-scope ACQUIRE load: a proper release/acquire pair, so the ordering does not rest on ISA
 // behaviour.  Its cost was measured at the DD shape: ~1.5 us per barrier.
 // The tickets are zeroed in stream order by an earlier launch of the same sequence (never by a memset node).
-constexpr int SM_SPIN_LIMIT = 1 << 20;
+constexpr int SM_SPIN_LIMIT = 1 << 22;
+constexpr int SM_BMAX16 = 8;      // whole-level kernels take B <= 128 graphs (16 lanes x 8 partial pairs per node)
+#ifdef DP_BAR_ACQREL
+#define SM_BAR_RELEASE __ATOMIC_RELEASE
+#define SM_BAR_ACQUIRE __ATOMIC_ACQUIRE
+#else
+#define SM_BAR_RELEASE __ATOMIC_RELAXED
+#define SM_BAR_ACQUIRE __ATOMIC_RELAXED
+#endif
 
 __device__ inline void sm_st_agent(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -436,17 +503,18 @@ __device__ inline float sm_ld_agent(const float* p) {
 }
 // returns false when the wait gave up.  `flag` is an LDS word.
 __device__ inline bool sm_grid_barrier(int* bar, int target, int* flag) {
-    __syncthreads();                        // every thread's exchange stores are issued and acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's exchange stores are acknowledged
+    __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(bar, 1, SM_BAR_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         int it = 0, ok = 1;
-        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (__hip_atomic_load(bar, SM_BAR_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
             if (++it > SM_SPIN_LIMIT) {
                 ok = 0;
                 __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(1);
         }
         *flag = ok;
     }
@@ -489,9 +557,9 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
     float* rs = mu + n;                    // [n]
     float* WL = rs + n;                    // all layers' weights, back to back
     float* BI = WL + a.wtot;               // all layers' biases (zeros where a layer has none)
-    float* PP = BI + a.btot;               // [B][n][2] partials of the layer being normalised
     const int tl = tid & 15, team = tid >> 4;
     const int NT = blockDim.x, NTEAMS = blockDim.x >> 4;
+    SM_STAMP(0, 7);
 
     // ---- one burst: adjacency, level input, every layer's weights and biases
     sm_dma(A, n * n, [&](int e) { return a.adj + (long)b * n * n + e; });
@@ -515,7 +583,9 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
             bo += dout;
         }
     }
+    SM_STAMP(0, 8);
     __syncthreads();
+    SM_STAMP(0, 9);
 
     int wo = 0, bo = 0;
     for (int l = 0; l < L; ++l) {
@@ -524,14 +594,17 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
         const float* W = WL + wo;
         const float* BL = BI + bo;
         // P = X W
-        lds_mma<false, false>(X, din, W, dout, n, dout, din, [&](int r, int c, float v) { P[r * dout + c] = v; });
+        lds_mma2<false, false>(X, din, W, dout, n, dout, din, [&](int r, int c, float v) { P[r * dout + c] = v; });
         __syncthreads();
+        SM_STAMP(0, 10 + 6 * l);
         // U = A P (+ P) + bias
-        lds_mma<false, false>(A, n, P, dout, n, dout, n, [&](int r, int c, float v) {
+        lds_mma2<false, false>(A, n, P, dout, n, dout, n, [&](int r, int c, float v) {
             if (a.add_self) v += P[r * dout + c];
             U[r * dout + c] = v + BL[c];
         });
+        if (l == 2) SM_STAMP(0, 30);
         __syncthreads();
+        SM_STAMP(0, 11 + 6 * l);
         // l2-normalise rows -> y (kept in U), saved output, BN partials of relu(y)
         const bool stats = !last && a.bn;
         float* part_l = a.part + (long)l * a.B * n * 2;
@@ -565,32 +638,43 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
                 }
             }
         }
+        SM_STAMP(0, 12 + 6 * l);
         if (last) break;
         if (stats) {
             // every graph's partials of this layer, then the statistics per node index (Chan combine)
             const bool ok = sm_grid_barrier(a.bar, (l + 1) * a.B, &bar_ok);
-            for (int e = tid; e < a.B * n * 2; e += NT) PP[e] = sm_ld_agent(part_l + e);
-            __syncthreads();
-            for (int r = tid; r < n; r += NT) {
+            SM_STAMP(0, 13 + 6 * l);
+            // one 16-lane team per node index: its B (mean, M2) pairs straight from the exchange buffer, one round trip
+            for (int r = team; r < n; r += NTEAMS) {
+                float pm[SM_BMAX16], pq[SM_BMAX16];
+#pragma unroll
+                for (int u = 0; u < SM_BMAX16; ++u) {
+                    const int bb = min(tl + 16 * u, a.B - 1);
+                    pm[u] = sm_ld_agent(part_l + ((long)bb * n + r) * 2);
+                    pq[u] = sm_ld_agent(part_l + ((long)bb * n + r) * 2 + 1);
+                }
                 float sm = 0.f;
-#pragma unroll 4
-                for (int bb = 0; bb < a.B; ++bb) sm += PP[(bb * n + r) * 2];
-                float m = sm / (float)a.B;
+#pragma unroll
+                for (int u = 0; u < SM_BMAX16; ++u) sm += (tl + 16 * u < a.B) ? pm[u] : 0.f;
+                float m = sm_team_sum(sm) / (float)a.B;
                 float s2 = 0.f;
-#pragma unroll 4
-                for (int bb = 0; bb < a.B; ++bb) {
-                    const float d = PP[(bb * n + r) * 2] - m;
-                    s2 += PP[(bb * n + r) * 2 + 1] + (float)dout * d * d;
+#pragma unroll
+                for (int u = 0; u < SM_BMAX16; ++u) {
+                    const float d = pm[u] - m;
+                    s2 += (tl + 16 * u < a.B) ? pq[u] + (float)dout * d * d : 0.f;
                 }
-                float rstd = 1.0f / sqrtf(s2 / ((float)a.B * (float)dout) + SM_BN_EPS);
+                float rstd = 1.0f / sqrtf(sm_team_sum(s2) / ((float)a.B * (float)dout) + SM_BN_EPS);
                 if (!ok) m = rstd = __builtin_nanf("");        // a barrier that gave up must not go unnoticed
-                if (b == 0) {
-                    a.stats[l][r * 2] = m;
-                    a.stats[l][r * 2 + 1] = rstd;
+                if (tl == 0) {
+                    if (b == 0) {
+                        a.stats[l][r * 2] = m;
+                        a.stats[l][r * 2 + 1] = rstd;
+                    }
+                    mu[r] = m;
+                    rs[r] = rstd;
                 }
-                mu[r] = m;
-                rs[r] = rstd;
             }
+            SM_STAMP(0, 14 + 6 * l);
         } else {
             for (int r = tid; r < n; r += NT) {
                 mu[r] = 0.f;
@@ -606,6 +690,7 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
                 a.Ze[((long)b * n + r) * a.ldz + a.coff[l] + k] = v;
             }
         __syncthreads();
+        SM_STAMP(0, 15 + 6 * l);
         wo += din * dout;
         bo += dout;
     }
@@ -659,7 +744,6 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
     float* M0 = P + n * a.omax;            // [n]
     float* M1 = M0 + n;                    // [n]
     float* DB = M1 + n;                    // [omax]
-    float* PP = DB + a.omax;               // [B][n][2]
     const int tl = tid & 15, team = tid >> 4;
     const int NT = blockDim.x, NTEAMS = blockDim.x >> 4;
 
@@ -728,18 +812,27 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
             }
             ++nbar;
             const bool ok = sm_grid_barrier(a.bar, nbar * a.B, &bar_ok);
-            for (int e = tid; e < a.B * n * 2; e += NT) PP[e] = sm_ld_agent(part_l + e);
-            __syncthreads();
-            for (int r = tid; r < n; r += NT) {
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-                for (int bb = 0; bb < a.B; ++bb) {
-                    s0 += PP[(bb * n + r) * 2];
-                    s1 += PP[(bb * n + r) * 2 + 1];
+            for (int r = team; r < n; r += NTEAMS) {
+                float p0[SM_BMAX16], p1[SM_BMAX16];
+#pragma unroll
+                for (int u = 0; u < SM_BMAX16; ++u) {
+                    const int bb = min(tl + 16 * u, a.B - 1);
+                    p0[u] = sm_ld_agent(part_l + ((long)bb * n + r) * 2);
+                    p1[u] = sm_ld_agent(part_l + ((long)bb * n + r) * 2 + 1);
                 }
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int u = 0; u < SM_BMAX16; ++u) {
+                    s0 += (tl + 16 * u < a.B) ? p0[u] : 0.f;
+                    s1 += (tl + 16 * u < a.B) ? p1[u] : 0.f;
+                }
+                s0 = sm_team_sum(s0);
+                s1 = sm_team_sum(s1);
                 const float cnt = (float)a.B * (float)dout;
-                M0[r] = ok ? s0 / cnt : __builtin_nanf("");
-                M1[r] = s1 / cnt;
+                if (tl == 0) {
+                    M0[r] = ok ? s0 / cnt : __builtin_nanf("");
+                    M1[r] = s1 / cnt;
+                }
             }
         }
         __syncthreads();
@@ -788,31 +881,31 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
         if (dbb)
             for (int c = tid; c < dout; c += NT) dbb[c] = DB[c];
         // G = A^T dU (+ dU);  P = X W (for dA)
-        lds_mma<true, false>(A, n, dU, dout, n, dout, n, [&](int m, int c, float v) {
+        lds_mma2<true, false>(A, n, dU, dout, n, dout, n, [&](int m, int c, float v) {
             G[m * dout + c] = a.add_self ? v + dU[m * dout + c] : v;
         });
         if (a.dadj)
-            lds_mma<false, false>(Xl, ldx, W, dout, n, dout, din, [&](int m, int c, float v) { P[m * dout + c] = v; },
+            lds_mma2<false, false>(Xl, ldx, W, dout, n, dout, din, [&](int m, int c, float v) { P[m * dout + c] = v; },
                                   ((n + 15) / 16) * ((dout + 15) / 16));
         __syncthreads();
         // dW = X^T G -> this graph's slab
         {
             float* dWb = a.slabs + (long)b * a.slab_stride + a.w_off[l];
-            lds_mma<true, false>(Xl, ldx, G, dout, din, dout, n, [&](int k, int c, float v) { dWb[k * dout + c] = v; });
+            lds_mma2<true, false>(Xl, ldx, G, dout, din, dout, n, [&](int k, int c, float v) { dWb[k * dout + c] = v; });
         }
         // gradient w.r.t. the layer input: G W^T
         if (l > 0) {
             float* dxin = DZ + a.coff[l - 1];
-            lds_mma<false, true>(G, dout, W, dout, n, din, dout, [&](int r, int k, float v) { dxin[r * D + k] += v; },
+            lds_mma2<false, true>(G, dout, W, dout, n, din, dout, [&](int r, int k, float v) { dxin[r * D + k] += v; },
                                  1);
         } else if (a.dX0) {
-            lds_mma<false, true>(G, dout, W, dout, n, din, dout, [&](int r, int k, float v) {
+            lds_mma2<false, true>(G, dout, W, dout, n, din, dout, [&](int r, int k, float v) {
                 a.dX0[((long)b * n + r) * d0 + k] = v;
             }, 1);
         }
         // dA += dU P^T
         if (a.dadj)
-            lds_mma<false, true>(dU, dout, P, dout, n, n, dout, [&](int r, int m, float v) { DA[r * n + m] += v; }, 2);
+            lds_mma2<false, true>(dU, dout, P, dout, n, n, dout, [&](int r, int m, float v) { DA[r * n + m] += v; }, 2);
         __syncthreads();
     }
     if (a.dadj)
@@ -881,7 +974,7 @@ static size_t small_level_lds_fwd(int B, int n, const int* dims, int L) {
         wtot += dims[l] * dims[l + 1];
         btot += dims[l + 1];
     }
-    return (size_t)n * n + (size_t)n * dmax + 2 * (size_t)n * omax + 2 * n + wtot + btot + (size_t)B * n * 2 + 16;
+    return (size_t)n * n + (size_t)n * dmax + 2 * (size_t)n * omax + 2 * n + wtot + btot + 64 + 16;
 }
 static size_t small_level_lds_bwd(int B, int n, const int* dims, int L, bool dadj) {
     int omax = 0, wtot = 0, D = 0;
@@ -891,7 +984,7 @@ static size_t small_level_lds_bwd(int B, int n, const int* dims, int L, bool dad
         D += dims[l + 1];
     }
     return (size_t)n * n * (dadj ? 2 : 1) + (size_t)n * dims[0] + 2 * (size_t)n * D + (size_t)(L - 1) * n * omax + wtot +
-           2 * (size_t)L * n + 3 * (size_t)n * omax + 2 * n + omax + (size_t)B * n * 2 + 16;
+           2 * (size_t)L * n + 3 * (size_t)n * omax + 2 * n + omax + 64 + 16;
 }
 static int device_cus() {
     static std::atomic<int> cus[64];
@@ -914,7 +1007,7 @@ bool small_level_fused_ok(int B, int n, const int* dims, int L, bool dadj) {
     if (small_level_lds_fwd(B, n, dims, L) * sizeof(float) > 150 * 1024) return false;
     if (small_level_lds_bwd(B, n, dims, L, dadj) * sizeof(float) > 150 * 1024) return false;
     const int cus = device_cus();
-    return cus > 0 && B <= cus / 2;
+    return cus > 0 && B <= cus / 2 && B <= 16 * SM_BMAX16;
 }
 size_t small_level_part_floats(int B, int n, int L) { return (size_t)(L > 1 ? L - 1 : 1) * B * n * 2; }
 

@@ -66,7 +66,7 @@ def test_softpool_against_reference_golden(name, golden):
             g64 = Pm[k].grad
             e_gpu = float((p.grad.detach().cpu().double() - g64).abs().max())
             e_ref = float((grads[k].double() - g64).abs().max())
-            assert e_gpu <= 4 * e_ref + 1e-7 * float(g64.abs().max()), \
+            assert e_gpu <= 4 * e_ref + 3e-7 * float(g64.abs().max()), \
                 f"{k}: |hip - fp64| {e_gpu:.3e} against the reference's own |fp32 - fp64| {e_ref:.3e}"
 
 
@@ -274,7 +274,9 @@ def test_er_full_size_properties():
 def test_gradients_no_worse_than_fp32_oracle_vs_fp64(tag, B, N, F_, H, Cc, ratio, p, linkpred, seed):
     """fp64-anchored gradient check (instead of a loose relative tolerance): the fp32 torch-CPU oracle is itself only
     an approximation of the exact gradient, so the HIP path is held to the oracle's own distance from an fp64 run of the
-    same restatement:  max|g_gpu - g64| <= 4 * max|g_oracle32 - g64| + 1e-7 * max|g64|  for EVERY parameter tensor.
+    same restatement:  max|g_gpu - g64| <= 4 * max|g_oracle32 - g64| + 3e-7 * max|g64|  for EVERY parameter tensor
+    (the floor is 5 ulp of the tensor's largest entry: for a bias gradient that is a 20-term sum the oracle's own error
+    can by luck be under one ulp, and 4x that is not a meaningful bound).
 
     One thing has to be equal on both sides first: the discrete decisions.  torch.max routes the readout gradient to
     the winning row, and at a pooled level rows tie to ~1e-8 (soft assignments are nearly uniform at init), so the
@@ -310,8 +312,8 @@ def test_gradients_no_worse_than_fp32_oracle_vs_fp64(tag, B, N, F_, H, Cc, ratio
         assert torch.isfinite(gg).all(), k
         e_gpu = float((gg - g64[k]).abs().max())
         e_o32 = float((g32[k] - g64[k]).abs().max())
-        bound = 4 * e_o32 + 1e-7 * float(g64[k].abs().max())
-        assert e_gpu <= bound, f"{tag} seed {seed} {k}: |gpu-fp64| {e_gpu:.3e} > 4*|oracle32-fp64| {e_o32:.3e} + 1e-7*scale"
+        bound = 4 * e_o32 + 3e-7 * float(g64[k].abs().max())
+        assert e_gpu <= bound, f"{tag} seed {seed} {k}: |gpu-fp64| {e_gpu:.3e} > 4*|oracle32-fp64| {e_o32:.3e} + 3e-7*scale"
 
 
 def test_adam_two_steps_golden(golden):
