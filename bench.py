@@ -130,6 +130,52 @@ def cpu_baseline(cpu, w, linkpred, budget_s=15.0):
                        f"{cands} intra-op threads ({dt:.1f} s at {t} threads; host has {ncpu} cpus)")
 
 
+def step_roofline(w, linkpred, ms_per_step, world=1):
+    """Step-level roofline: roofline.achieved = max(t_HBM, t_MFMA) / t_measured, from SURVEY §8(d)'s
+    algorithmic per-graph figures — FLOPs forward = sum over GCN stacks and layers of (2 n^2 f_l + 2 n f_l f_{l+1}) +
+    assign heads 2 n Da K + pooling 2 K n^2 + 2 K^2 n + 2 K n D (+ link loss 2 N^2 K), fwd+bwd = 3 x fwd; bytes = the
+    level-0 adjacency passes (2L+1 forward, 2(L-1)+1 backward, +1 each with the link loss) at the element size THIS
+    build reads (bf16 copies written once from the fp32 input when N >= 128, fp32 otherwise) + 8 N (D + Da + K) x 3
+    bytes of activations — against 8.0 TB/s HBM and 2.5 PFLOP/s dense bf16 MFMA."""
+    N, F_, H, L = w["N"], w["F"], w["H"], 3
+    P = w.get("num_pooling", 1) if w.get("model") != "set2set" else 0
+    D = H * L
+    packed = N >= 128
+
+    def stack(n, fin, hid, fout):
+        dims = [fin] + [hid] * (L - 1) + [fout]
+        return sum(2.0 * n * n * dims[l] + 2.0 * n * dims[l] * dims[l + 1] for l in range(L))
+    flops = stack(N, F_, H, H)
+    n, fa = N, F_
+    K0 = Da0 = 0
+    for j in range(P):
+        K = int(n * w["ratio"])
+        Da = H * (L - 1) + K
+        if j == 0:
+            K0, Da0 = K, Da
+        flops += stack(n, fa, H, K) + 2.0 * n * Da * K                      # assign stack + head
+        flops += 2.0 * K * n * n + 2.0 * K * K * n + 2.0 * K * n * D        # pooling
+        flops += stack(K, D, H, H)                                          # embed after pool
+        n, fa = K, D
+    if linkpred and P:
+        flops += 2.0 * N * N * K0
+    flops *= 3.0
+    pf, pb = 2 * L + 1 + (1 if linkpred else 0), 2 * (L - 1) + 1 + (1 if linkpred else 0)
+    if P == 0:
+        pf, pb = L, L - 1
+    s_a = 2 if packed else 4
+    adj_bytes = (pf + pb) * N * N * s_a + (N * N * (4 + 2 * 2) if packed else 0)
+    act_bytes = 8.0 * N * (D + Da0 + K0) * 3
+    per_graph = adj_bytes + act_bytes
+    B = w["B"] * world
+    t_hbm = per_graph * B / (HBM_PEAK_GBS * 1e9) * 1e6 / world
+    t_mfma = flops * B / (MFMA_BF16_PEAK_TF * 1e12) * 1e6 / world
+    t_meas = ms_per_step * 1e3
+    return dict(t_hbm_us=round(t_hbm, 2), t_mfma_us=round(t_mfma, 3), achieved=round(max(t_hbm, t_mfma) / t_meas, 4),
+                bytes_per_graph=int(per_graph), flops_per_graph=int(flops), adjacency_bytes_per_element=s_a,
+                adjacency_passes=pf + pb, note="per GPU; HBM 8.0 TB/s, bf16 MFMA 2.5 PFLOP/s dense")
+
+
 def roofline_probe(w, device, iters=200):
     """Average duration of the dominant kernel, HIP events on the launch stream: the level-0 adjacency
     aggregation  U[b] = A[b] (N x N) · V[b] (N x C),  C = H_embed + H_assign, exactly as the encoder plan runs it
@@ -381,6 +427,7 @@ def main():
                 out["roofline_hbm"] = roofline_probe(w, device)
             else:
                 out["roofline"] = roofline_probe(w, device)
+            out["roofline"]["step"] = step_roofline(w, args.linkpred, ms)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cpu, w, args.linkpred)
         print(json.dumps(out))

@@ -231,6 +231,11 @@ void rownorm_fwd(Seq& q, const float* U, int ldu, const float* P /*add_self or n
                  int normalize, int relu_stats);
 void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* part /*[B,n,G,2]; null: no BN*/, float* stats,
                   RowGroups g, GroupPtrs xout, int B, int n, int relu);
+// apply_bn of one layer + the next layer's transform P = x W in one launch (row-local; small batches, widths <= 64)
+bool bn_transform_supported(RowGroups gin, RowGroups gout, int B);
+void bn_transform_fwd(Seq& q, const float* Y, int ldy, const float* part, float* stats, RowGroups gin, GroupPtrs xout,
+                      const float* const W[2], RowGroups gout, float* P, int ldp, int B, int n, int relu,
+                      unsigned short* vs /*also emit the 3-plane bf16 split of P, or null*/);
 void mask_rows(Seq& q, const float* src, int lds, float* dst, int ldd, const int* num_nodes, int B, int n, int F);
 void bn_bwd_partials(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, RowGroups g, float* part, long rows);
 void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat /*BN output, null when no BN*/, GroupCPtrs y,

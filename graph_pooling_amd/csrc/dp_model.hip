@@ -384,6 +384,7 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
         }
         return;
     }
+    bool transformed = false;      // layer l's P = x W was already written by the previous layer's BN launch
     for (int l = 0; l < li.L; ++l) {
         const int ct = li.ctot[l];
         const bool last = l == li.L - 1;
@@ -393,7 +394,8 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
             q.fold_zero_p = io.pack->flag;
             q.fold_zero_n16 = 16;
         }
-        transform(q, c, li, lv, io, params, l, Pj, presplit ? vs : nullptr);
+        if (!transformed) transform(q, c, li, lv, io, params, l, Pj, presplit ? vs : nullptr);
+        transformed = false;
         if (l == 0 && io.pack) {
             const bool folded = q.fold_zero_p == nullptr;      // consumed by the GEMM launch
             q.fold_zero_p = nullptr;
@@ -432,7 +434,20 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
             xout.ld[0] = li.D;
             xout.p[1] = li.a ? lv.Za + li.coff_a[l] : nullptr;
             xout.ld[1] = li.Da;
-            bn_apply_fwd(q, lv.layer[l].Y, ct, bn ? part : nullptr, lv.layer[l].stats, g, xout, B, n, 1);
+            // apply_bn and the NEXT layer's transform in one launch when that transform is a plain row-local product
+            const RowGroups gnext = groups_of(li, l + 1);
+            bool plain_next = !knobs().no_level_fusion && bn_transform_supported(g, gnext, B);
+            for (int gi = 0; gi < li.G; ++gi) plain_next = plain_next && !drop_mask(li, io, gi, l + 1);
+            if (plain_next) {
+                const float* Wn[2] = {PW(params, li.e->w_off[l + 1]), li.a ? PW(params, li.a->w_off[l + 1]) : nullptr};
+                const int ctn = li.ctot[l + 1];
+                const bool presplit_n = pk && vs && aggregate_packed_usable(io.adj, n, ctn);
+                bn_transform_fwd(q, lv.layer[l].Y, ct, bn ? part : nullptr, lv.layer[l].stats, g, xout, Wn, gnext, Pj,
+                                 ctn, B, n, 1, presplit_n ? vs : nullptr);
+                transformed = true;
+            } else {
+                bn_apply_fwd(q, lv.layer[l].Y, ct, bn ? part : nullptr, lv.layer[l].stats, g, xout, B, n, 1);
+            }
         }
     }
 }

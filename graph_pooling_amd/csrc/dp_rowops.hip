@@ -226,6 +226,182 @@ void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* part, float* sta
     q.check_launch("bn_apply_fwd");
 }
 
+// ------------------------------------------------------------------ bn apply + next layer's transform
+// apply_bn of layer l (as k_bn_apply_fwd) AND the next GraphConv's feature transform P = x W (encoders.py:968 with the
+// product re-associated, A (x W)) in one launch: the transform is row-local and tiny (20 x 20 .. 64 x 64 per group),
+// so as a GEMM launch of its own it was ~6 us of launch floor and LDS staging per layer.  grid (16-row chunks, B):
+// a 16-lane team normalises one row (both column groups), the rows meet the group's weights in LDS, and — when the
+// aggregation that follows runs on the packed adjacency — the workgroup also writes the exact 3-plane bf16 split of
+// its 16 rows of P (two k8 groups; the last chunk writes the zero groups that pad n to a multiple of 32).
+struct BnTransformArgs {
+    BnApplyArgs bn;
+    const float* W[2];       // per group: [w_in, w_out] row-major
+    RowGroups gout;          // output column groups of P
+    float* P;                // [B, n, ldp]
+    int ldp;
+    unsigned short* vs;
+    int vs_ct, vs_k8;
+};
+template <int NK>
+__global__ __launch_bounds__(256) void k_bn_transform(BnTransformArgs t) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const BnApplyArgs& a = t.bn;
+    const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int G = a.g.G;
+    const int cin = a.g.c0[G - 1] + a.g.w[G - 1];
+    const int cout = t.gout.c0[G - 1] + t.gout.w[G - 1];
+    const int wcnt0 = a.g.w[0] * t.gout.w[0], wcnt1 = G == 2 ? a.g.w[1] * t.gout.w[1] : 0;
+    float* WL = lds;                         // both groups' weights
+    float* XT = WL + wcnt0 + wcnt1;          // [16][cin]
+    float* PT = XT + 16 * cin;               // [16][cout]
+    // (1) weights: everything in flight before anything is used
+    {
+        constexpr int WR = 4;
+        for (int e0 = 0; e0 < wcnt0 + wcnt1; e0 += 256 * WR) {
+            float w[WR];
+#pragma unroll
+            for (int u = 0; u < WR; ++u) {
+                const int e = min(e0 + u * 256 + (int)threadIdx.x, wcnt0 + wcnt1 - 1);
+                w[u] = e < wcnt0 ? t.W[0][e] : t.W[1][e - wcnt0];
+            }
+#pragma unroll
+            for (int u = 0; u < WR; ++u) {
+                const int e = e0 + u * 256 + (int)threadIdx.x;
+                if (e < wcnt0 + wcnt1) WL[e] = w[u];
+            }
+        }
+    }
+    // (2) the team's row: BatchNorm of both groups (exactly k_bn_apply_fwd's arithmetic)
+    const int node = chunk * 16 + team;
+    const bool live = node < a.n;
+    const long row = (long)b * a.n + min(node, a.n - 1);
+    for (int g = 0; g < G; ++g) {
+        const int w = a.g.w[g];
+        const float* y = a.Y + row * a.ldy + a.g.c0[g];
+        float yv[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) yv[k] = y[min(tl + 16 * k, w - 1)];
+        float mu = 0.f, rstd = 1.f;
+        const int nd = min(node, a.n - 1);
+        if (a.part && a.stats_ready) {
+            mu = a.stats[((long)nd * G + g) * 2];
+            rstd = a.stats[((long)nd * G + g) * 2 + 1];
+        } else if (a.part) {
+            const long pstride = (long)a.n * G * 2;
+            const float* p = a.part + ((long)nd * G + g) * 2;
+            float pm[2], pq[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long o = (long)min(tl + 16 * u, a.B - 1) * pstride;
+                pm[u] = p[o];
+                pq[u] = p[o + 1];
+            }
+            float sm = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) sm += (tl + 16 * u < a.B) ? pm[u] : 0.f;
+            mu = team_sum(sm) / (float)a.B;
+            float s2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float d = pm[u] - mu;
+                s2 += (tl + 16 * u < a.B) ? pq[u] + (float)w * d * d : 0.f;
+            }
+            const float var = team_sum(s2) / ((float)a.B * (float)w);
+            rstd = 1.0f / sqrtf(var + BN_EPS);
+            if (live && b == 0 && tl == 0) {
+                a.stats[((long)nd * G + g) * 2] = mu;
+                a.stats[((long)nd * G + g) * 2 + 1] = rstd;
+            }
+        }
+        float* x = a.xout.p[g] + row * a.xout.ld[g];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int c = tl + 16 * k;
+            const float v = a.relu ? fmaxf(yv[k], 0.f) : yv[k];
+            const float xv = (v - mu) * rstd;
+            if (c < w) {
+                if (live) x[c] = xv;
+                XT[team * cin + a.g.c0[g] + c] = live ? xv : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    // (3) P = x W per group: one output element per thread and pass, the row broadcast from LDS
+    for (int o = threadIdx.x; o < 16 * cout; o += 256) {
+        const int r = o / cout, c = o - r * cout;
+        const int g = (G == 2 && c >= t.gout.c0[1]) ? 1 : 0;
+        const int win = a.g.w[g], wout = t.gout.w[g];
+        const float* xr = XT + r * cin + a.g.c0[g];
+        const float* wc = WL + (g ? wcnt0 : 0) + (c - t.gout.c0[g]);
+        float acc = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < win; ++k) acc = fmaf(xr[k], wc[k * wout], acc);
+        PT[o] = acc;
+        const int nd = chunk * 16 + r;
+        if (nd < a.n) t.P[((long)b * a.n + nd) * t.ldp + c] = acc;
+    }
+    if (!t.vs) return;
+    __syncthreads();
+    unsigned short* vb = t.vs + (long)b * 3 * t.vs_ct * t.vs_k8 * 128;
+    const long pl = (long)t.vs_ct * t.vs_k8 * 128;
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    const int kend = chunk == (int)gridDim.x - 1 ? t.vs_k8 : 2 * chunk + 2;
+    for (int item = threadIdx.x; item < (kend - 2 * chunk) * t.vs_ct * 16; item += 256) {
+        const int k8 = 2 * chunk + item / (t.vs_ct * 16), vc = item % (t.vs_ct * 16);
+        const int lr = (k8 - 2 * chunk) * 8;
+        u16x8 h, m, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = (lr < 16 && vc < cout) ? PT[(lr + j) * cout + vc] : 0.f;   // rows past n were computed from 0
+            unsigned short hh, mm, ll;
+            bf16_split3(v, hh, mm, ll);
+            h[j] = hh; m[j] = mm; l[j] = ll;
+        }
+        const long o = vs_index(0, t.vs_ct, t.vs_k8, vc >> 4, k8, vc & 15, 0);
+        *reinterpret_cast<u16x8*>(vb + o) = h;
+        *reinterpret_cast<u16x8*>(vb + o + pl) = m;
+        *reinterpret_cast<u16x8*>(vb + o + 2 * pl) = l;
+    }
+}
+bool bn_transform_supported(RowGroups gin, RowGroups gout, int B) {
+    const int G = gin.G;
+    if (B > 32) return false;                 // (bigger batches finalise the statistics in a launch of their own)
+    size_t wfl = 0;
+    for (int g = 0; g < G; ++g) {
+        if (gin.w[g] > 64 || gout.w[g] > 128) return false;
+        wfl += (size_t)gin.w[g] * gout.w[g];
+    }
+    const int cin = gin.c0[G - 1] + gin.w[G - 1], cout = gout.c0[G - 1] + gout.w[G - 1];
+    return (wfl + 16 * (size_t)(cin + cout)) * sizeof(float) <= 60 * 1024;
+}
+// part == null: no BN (relu only).  W[g]: [gin.w[g], gout.w[g]].
+void bn_transform_fwd(Seq& q, const float* Y, int ldy, const float* part, float* stats, RowGroups gin, GroupPtrs xout,
+                      const float* const W[2], RowGroups gout, float* P, int ldp, int B, int n, int relu,
+                      unsigned short* vs) {
+    if (!q.ok()) return;
+    BnTransformArgs t{};
+    t.bn = BnApplyArgs{Y, ldy, part, stats, gin, xout, B, n, relu, 0};
+    t.W[0] = W[0];
+    t.W[1] = W[1];
+    t.gout = gout;
+    t.P = P;
+    t.ldp = ldp;
+    t.vs = vs;
+    const int G = gin.G;
+    const int cin = gin.c0[G - 1] + gin.w[G - 1], cout = gout.c0[G - 1] + gout.w[G - 1];
+    t.vs_ct = (cout + 15) / 16;
+    t.vs_k8 = ((n + 31) / 32) * 4;
+    size_t wfl = 0;
+    for (int g = 0; g < G; ++g) wfl += (size_t)gin.w[g] * gout.w[g];
+    const size_t lds = (wfl + 16 * (size_t)(cin + cout)) * sizeof(float);
+    const int maxw = G == 2 && gin.w[1] > gin.w[0] ? gin.w[1] : gin.w[0];
+    const dim3 grid((n + 15) / 16, B);
+    if (maxw <= 32) hipLaunchKernelGGL(k_bn_transform<2>, grid, dim3(256), lds, q.stream, t);
+    else hipLaunchKernelGGL(k_bn_transform<4>, grid, dim3(256), lds, q.stream, t);
+    q.check_launch("bn_transform");
+}
+
 // ------------------------------------------------------------------ bn bwd partials
 // per (row, group): sum_f dx, sum_f dx * xhat
 struct BnBwdPartArgs {
