@@ -306,6 +306,9 @@ def main():
     ap.add_argument("--linkpred", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval", action="store_true",
+                    help="time the forward-only evaluation step (model.predict: DP_MODE_EVAL forward + on-device arg-max, "
+                         "train.py:30-58) instead of forward + loss + backward")
     ap.add_argument("--probe-only", action="store_true",
                     help="run only the roofline probe (used to profile the dominant kernel in isolation)")
     args = ap.parse_args()
@@ -347,6 +350,8 @@ def main():
         dp = DataParallelEncoder(model)
 
     def fwd_bwd():
+        if args.eval:
+            return model.predict(batch["x"], batch["adj"], batch["nn"], assign_x=batch["x"])
         model.zero_grad(set_to_none=True)
         ypred = model(batch["x"], batch["adj"], batch["nn"], assign_x=batch["x"])
         if args.linkpred:
@@ -410,8 +415,9 @@ def main():
         ms = dt / args.steps * 1e3
         value = w["B"] * world * args.steps / dt
         out = {
-            "metric": "graphs/sec fwd+bwd, DD padded batch N_max=500" if args.workload == "dd"
-                      else f"graphs/sec fwd+bwd, {args.workload}",
+            "metric": (f"graphs/sec forward-only evaluation (predict), {args.workload}" if args.eval else
+                       "graphs/sec fwd+bwd, DD padded batch N_max=500" if args.workload == "dd"
+                       else f"graphs/sec fwd+bwd, {args.workload}"),
             "value": round(value, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -420,7 +426,7 @@ def main():
                        "linkpred": bool(args.linkpred), "hip_graph": graph is not None,
                        "parallelism": f"dp{world}"},
         }
-        if world == 1:
+        if world == 1 and not args.eval:
             if w.get("roofline") == "mfma":
                 # the ER workload is the MFMA-bound one: its dominant kernel is the wide pooling product
                 out["roofline"] = mfma_probe(w, device)

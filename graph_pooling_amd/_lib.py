@@ -96,7 +96,7 @@ _PROTOS = {
     "dp_encoder_save_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "dp_encoder_workspace_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "dp_encoder_save_locate": (_I, [C.POINTER(EncoderCfg), _I, _I, C.POINTER(_Z), C.POINTER(_Z)]),
-    "dp_encoder_forward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
+    "dp_encoder_forward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
     "dp_encoder_backward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
     "dp_build_batch": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dp_clip_adam_workspace_bytes": (_Z, []),

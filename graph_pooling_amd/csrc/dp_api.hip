@@ -63,7 +63,7 @@ void ensure_dyn_lds(Seq& q, DynLdsOnce& st, const void* fn, int bytes, const cha
 // dp_model.hip
 int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                     const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
-                    float* assign_out, void* save, int mode);
+                    float* assign_out, void* save, int mode, long long* labels_out);
 int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                      const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
                      const float* d_assign, float* grads, const void* save, int prezeroed);
@@ -530,7 +530,7 @@ size_t dp_encoder_save_bytes(const dp_encoder_cfg* cfg) {
 }
 size_t dp_encoder_workspace_bytes(const dp_encoder_cfg* cfg) {
     if (encoder_validate(cfg) != DP_OK) return 0;
-    size_t f = sized([&](Seq& q) { encoder_forward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0, DP_MODE_TRAIN); });
+    size_t f = sized([&](Seq& q) { encoder_forward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0, DP_MODE_TRAIN, 0); });
     size_t b = sized([&](Seq& q) { encoder_backward(q, *cfg, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0); });
     return f > b ? f : b;
 }
@@ -543,8 +543,8 @@ int dp_encoder_save_locate(const dp_encoder_cfg* cfg, int level, int field, size
 }
 int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
                        const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
-                       float* assign_out, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
-                       int mode, void* stream) {
+                       float* assign_out, long long* labels_out, void* save, size_t save_bytes, void* workspace,
+                       size_t workspace_bytes, int mode, void* stream) {
     int rc = encoder_validate(cfg);
     if (rc != DP_OK) return rc;
     NOTNULL(params); NOTNULL(x); NOTNULL(adj); NOTNULL(ypred); NOTNULL(save);
@@ -553,7 +553,8 @@ int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const flo
                  encoder_save_bytes(*cfg));
     Seq q(STREAM(stream), workspace, workspace_bytes);
     DP_CHECK_ARG((mode & ~(DP_MODE_TRAIN)) == 0, "mode=%d: DP_MODE_EVAL or DP_MODE_TRAIN", mode);
-    return encoder_forward(q, *cfg, params, x, adj, assign_x, num_nodes, dropout, ypred, assign_out, save, mode);
+    return encoder_forward(q, *cfg, params, x, adj, assign_x, num_nodes, dropout, ypred, assign_out, save, mode,
+                           labels_out);
 }
 int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
                         const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,

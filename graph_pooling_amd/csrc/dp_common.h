@@ -259,6 +259,7 @@ void masked_max_fwd(Seq& q, const float* Z, int ldz, const int* num_nodes, float
 void masked_max_bwd(Seq& q, const float* dout, int ldo, const int* argmax, int lda, float* dZ, int ldz, int B,
                     int n, int F);
 void relu_bwd_inplace(Seq& q, float* d, const float* h, long count);
+void argmax_rows(Seq& q, const float* X, int ldx, long long* out, int rows, int cols);   // first index on ties
 void ce_fwd(Seq& q, const float* logits, const long long* label, float* loss, float* prob, int B, int C,
             float* also_zero = nullptr /*a second scalar to clear in the same launch*/,
             float* dunit = nullptr /*[B, C]: d loss / d logits for an upstream gradient of 1*/);
@@ -343,6 +344,7 @@ struct HeadArgs {
     long w_off[DP_MAX_PRED + 1], b_off[DP_MAX_PRED + 1];
     float* hid[DP_MAX_PRED + 2];   // hid[0] = features [B, dims[0]], hid[i] = post-ReLU activations, hid[n_pred] = ypred
     int B;
+    long long* labels;             // optional: arg-max class per graph (evaluation)
 };
 struct HeadBwdArgs {
     HeadArgs h;              // dims / offsets / saved activations (hid[] read-only here)

@@ -244,6 +244,15 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
         wo += din * dout;
         bo += dout;
     }
+    // evaluation: the predicted class leaves the device as ONE integer per graph (`torch.max(ypred, 1)` +
+    // `.cpu()` of B x C logits in the reference's evaluate(), train.py:42-44); first index on ties
+    if (a.labels && threadIdx.x == 0) {
+        const int C = a.dims[a.n_pred];
+        int best = 0;
+        for (int c = 1; c < C; ++c)
+            if (cur[c] > cur[best]) best = c;
+        a.labels[b] = best;
+    }
     HEAD_STAMP(3);
 }
 

@@ -676,7 +676,7 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
 
 int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                     const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
-                    float* assign_out, void* save, int mode) {
+                    float* assign_out, void* save, int mode, long long* labels_out) {
     SaveLayout sv = layout_save(c, save);
     const BwdZero bz = alloc_bwd_zero(q, c);      // same offsets as in encoder_backward: first block of the workspace
     Scratch sc = fwd_scratch(q, c);
@@ -698,6 +698,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
     int featoff = 0;
     const bool fused_head = head_usable(c);
     HeadArgs head = head_args(c, sv, params, ypred);
+    head.labels = labels_out;
     // grid-barrier tickets of a whole-level kernel: cleared in stream order by the softmax launch of the level below
     // (together with its split-K tickets); a small level 0 has no such launch in front of it and clears its own
     int* level_bar = nullptr;
@@ -789,6 +790,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
               c.pred_dims[i], c.pred_dims[i], c.pred_dims[i], c.pred_dims[i + 1], 0, 0, 0, false, true, 1.f, 0.f,
               lastl ? 0 : 1);
     }
+    if (labels_out) argmax_rows(q, ypred, c.pred_dims[c.n_pred], labels_out, B, c.pred_dims[c.n_pred]);
     return q.err;
 }
 

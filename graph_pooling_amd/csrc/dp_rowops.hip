@@ -1219,6 +1219,23 @@ void ce_bwd(Seq& q, const float* prob, const long long* label, const float* dlos
     q.check_launch("ce_bwd");
 }
 
+// out[r] = argmax_c X[r, c] (first index on ties) — evaluate()'s torch.max(ypred, 1), train.py:43, for the plans whose
+// prediction head is not the fused kernel
+__global__ void k_argmax_rows(const float* X, int ldx, long long* out, int rows, int cols) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* x = X + (long)r * ldx;
+    int best = 0;
+    for (int c = 1; c < cols; ++c)
+        if (x[c] > x[best]) best = c;
+    out[r] = best;
+}
+void argmax_rows(Seq& q, const float* X, int ldx, long long* out, int rows, int cols) {
+    if (!q.ok() || rows <= 0) return;
+    hipLaunchKernelGGL(k_argmax_rows, dim3((rows + 255) / 256), dim3(256), 0, q.stream, X, ldx, out, rows, cols);
+    q.check_launch("argmax_rows");
+}
+
 // ------------------------------------------------------------------ slab reduce
 // out[p] (+)= sum_b slabs[b, p]   — per-graph parameter-gradient slabs -> the flat gradient buffer
 __global__ __launch_bounds__(1024) void k_reduce_slabs(const float* slabs, long stride, int B, float* out,

@@ -125,7 +125,7 @@ class _EncoderFn(torch.autograd.Function):
     """One FFI call per pass: dp_encoder_forward / dp_encoder_backward."""
 
     @staticmethod
-    def forward(ctx, owner, x, adj, assign_x, num_nodes, drop, needs_grad, *params):
+    def forward(ctx, owner, x, adj, assign_x, num_nodes, drop, needs_grad, labels, *params):
         # needs_grad is decided by the caller: grad mode is always off inside Function.forward
         lib = _lib.load()
         plan = owner._plan(x.shape[0], x.shape[1], x.device)
@@ -138,7 +138,7 @@ class _EncoderFn(torch.autograd.Function):
         stream = _lib.current_stream()
         _lib.check(lib.dp_encoder_forward(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(), adj.data_ptr(),
                                           _lib.ptr(assign_x), _lib.ptr(num_nodes), _lib.ptr(drop), ypred.data_ptr(),
-                                          _lib.ptr(assign), save.data_ptr(), plan.save_bytes,
+                                          _lib.ptr(assign), _lib.ptr(labels), save.data_ptr(), plan.save_bytes,
                                           plan.workspace.data_ptr(), plan.ws_bytes,
                                           _lib.MODE_TRAIN if needs_grad else _lib.MODE_EVAL, stream),
                    "dp_encoder_forward")
@@ -172,7 +172,7 @@ class _EncoderFn(torch.autograd.Function):
                                            plan.save_bytes, plan.workspace.data_ptr(), plan.ws_bytes, prezeroed,
                                            _lib.current_stream()), "dp_encoder_backward")
         owner._last_flat_grad = grads
-        out = [None, None, None, None, None, None, None]
+        out = [None, None, None, None, None, None, None, None]
         for (off, numel, shape) in owner._flat_index:
             out.append(grads[off:off + numel].view(shape))
         return tuple(out)
@@ -415,7 +415,7 @@ class GcnEncoderGraph(nn.Module):
             drop[off:off + numel].bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
         return drop
 
-    def _run(self, x, adj, batch_num_nodes, assign_x=None):
+    def _run(self, x, adj, batch_num_nodes, assign_x=None, labels=None):
         _lib.require_gpu_tensor(x, "x")
         _lib.require_gpu_tensor(adj, "adj")
         if x.dim() != 3 or adj.dim() != 3 or adj.shape[1] != adj.shape[2] or adj.shape[:2] != x.shape[:2]:
@@ -432,7 +432,7 @@ class GcnEncoderGraph(nn.Module):
         if drop is None:
             drop = self._draw_dropout(self._plan(x.shape[0], x.shape[1], x.device), x.device)
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params)
-        return _EncoderFn.apply(self, x, adj, assign_x, nn_dev, drop, needs_grad, *self._flat_params)
+        return _EncoderFn.apply(self, x, adj, assign_x, nn_dev, drop, needs_grad, labels, *self._flat_params)
 
     # -- reference surface
     def construct_mask(self, max_nodes, batch_num_nodes):
@@ -446,7 +446,7 @@ class GcnEncoderGraph(nn.Module):
     def forward(self, x, adj, batch_num_nodes=None, **kwargs):
         if x.shape[2] != self.input_dim:
             raise ValueError(f"x has {x.shape[2]} features, the encoder was built for {self.input_dim}")
-        return self._run(x, adj, batch_num_nodes)
+        return self._run(x, adj, batch_num_nodes, labels=getattr(self, "_predict_labels", None))
 
     def saved_activation(self, level, what):
         """A view of one activation the LAST forward call kept in its save buffer: what in {'assign', 'xpool',
@@ -477,9 +477,16 @@ class GcnEncoderGraph(nn.Module):
     @torch.no_grad()
     def predict(self, x, adj, batch_num_nodes=None, **kwargs):
         """The reference's evaluate() inner loop (train.py:42-44: forward, `torch.max(ypred, 1)`, `.cpu()`), kept on
-        the device: forward under no_grad (activations go to one reusable buffer, nothing is kept for backward)
-        and the arg-max as an int64 [B] device tensor — the caller moves B integers, not B x C logits."""
-        return self.forward(x, adj, batch_num_nodes, **kwargs).argmax(dim=1)
+        the device: a DP_MODE_EVAL forward (activations go to one reusable buffer, nothing is prepared for a backward
+        pass) whose prediction-head launch also writes the arg-max class as an int64 [B] device tensor — the caller
+        moves B integers, not B x C logits, and no arg-max launch runs."""
+        labels = torch.empty(x.shape[0], device=x.device, dtype=torch.int64)
+        self._predict_labels = labels
+        try:
+            self.forward(x, adj, batch_num_nodes, **kwargs)
+        finally:
+            self._predict_labels = None
+        return labels
 
     def loss(self, pred, label, type='softmax'):
         if type == 'softmax':
@@ -748,7 +755,7 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
         if x.shape[2] != self.input_dim or x_a.shape[2] != self.assign_input_dim:
             raise ValueError(f"feature widths {x.shape[2]}/{x_a.shape[2]} do not match the model "
                              f"({self.input_dim}/{self.assign_input_dim})")
-        ypred, assign = self._run(x, adj, batch_num_nodes, assign_x=x_a)
+        ypred, assign = self._run(x, adj, batch_num_nodes, assign_x=x_a, labels=getattr(self, "_predict_labels", None))
         # level-0 assignment [B, N, K_0]; == the reference's attribute when num_pooling == 1
         self.assign_tensor = assign
         return ypred

@@ -257,10 +257,12 @@ int dp_encoder_save_locate(const dp_encoder_cfg* cfg, int level, int field, size
                             clears the backward pass's accumulators (they live at the start of the workspace) on the side
                             of its adjacency-pack kernel, so the backward may be called with prezeroed = 1 — provided
                             nothing else used that workspace in between and it is the first backward of this forward */
+/* labels_out: int64 [B] or NULL — the arg-max class of every graph (first index on ties), written by the prediction
+ * head's own launch: evaluate() (train.py:42-44) moves B integers to the host instead of B x C logits. */
 int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const float* x, const float* adj,
                        const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
-                       float* assign_out, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
-                       int mode, void* stream);
+                       float* assign_out, long long* labels_out, void* save, size_t save_bytes, void* workspace,
+                       size_t workspace_bytes, int mode, void* stream);
 /* d_ypred [B,label_dim]; d_assign [B,N,K_0] or NULL (gradient arriving at the level-0 assignment
  * from the link-prediction loss); grads: flat, same layout as params, OVERWRITTEN.
  * prezeroed: 1 iff the accumulators were cleared by a DP_MODE_TRAIN forward (see above); 0: this call clears them. */

@@ -354,6 +354,30 @@ def test_eval_mode_and_no_grad_match_train_forward():
     assert torch.equal(labels, y1.argmax(dim=1))
 
 
+def test_predict_matches_reference_argmax_on_the_enzymes_batch(golden):
+    """N3 / train.py:30-58: evaluate() = forward + torch.max(ypred, 1).  predict() runs a DP_MODE_EVAL forward whose
+    head launch writes the class ids; on the real-ENZYMES fixture (G9) they must equal the arg-max of the reference's
+    own ypred, and the logits of the eval forward must be the training forward's bit for bit."""
+    a, params, _ = golden("g9_enzymes_batch")
+    x = T(a["x"])
+    B, N, F_ = x.shape
+    adj = T(np.unpackbits(a["adj_bits"], axis=-1)[..., :N].astype(np.float32))
+    model = SoftPoolingGcnEncoder(N, F_, 20, 20, 6, 3, 20, assign_ratio=0.1, linkpred=True)
+    model.load_state_dict(params)
+    model = model.cuda().eval()
+    xd, ad = x.cuda(), adj.cuda()
+    labels = model.predict(xd, ad, a["num_nodes"], assign_x=xd)
+    assert labels.dtype == torch.int64 and labels.shape == (B,)
+    assert torch.equal(labels.cpu(), T(a["ypred"]).argmax(dim=1))
+    y_train = model(xd, ad, a["num_nodes"], assign_x=xd)              # grad mode: DP_MODE_TRAIN forward
+    with torch.no_grad():
+        y_eval = model(xd, ad, a["num_nodes"], assign_x=xd)
+    assert torch.equal(y_train, y_eval) and torch.equal(labels, y_eval.argmax(dim=1))
+    # a plan whose prediction head is not the fused kernel (Set2Set readout) takes the arg-max kernel instead
+    s2s = GcnSet2SetEncoder(F_, 8, 8, 6, 3).cuda()
+    assert torch.equal(s2s.predict(xd, ad, a["num_nodes"]), s2s(xd, ad, a["num_nodes"]).argmax(dim=1))
+
+
 def test_two_forwards_before_their_backwards():
     """Each training forward keeps its own activations, and only the latest forward may hand its pre-cleared
     accumulators to a backward pass (DP_MODE_TRAIN / prezeroed): fwd(a), fwd(b), bwd(a), bwd(b) — and a second backward
