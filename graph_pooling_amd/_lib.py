@@ -46,7 +46,14 @@ class EncoderCfg(C.Structure):
                 ("s2s_off", C.c_long * 6),
                 ("mask_readout", C.c_int),
                 ("n_params", C.c_long),
-                ("n_graph_params", C.c_long)]
+                ("n_graph_params", C.c_long),
+                ("bn_world", C.c_int),
+                ("exchange", C.c_void_p),
+                ("exchange_user", C.c_void_p)]
+
+
+# int (*dp_exchange_fn)(void* user, const void* local, void* gathered, size_t bytes_per_rank, void* stream)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 _P = C.c_void_p
@@ -102,8 +109,8 @@ _PROTOS = {
     "dp_clip_adam_workspace_bytes": (_Z, []),
     "dp_clip_adam_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P, _P, _Z, _P]),
     "dp_loss_workspace_bytes": (_Z, [_I, _I, _I, _I]),
-    "dp_loss_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
-    "dp_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "dp_loss_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "dp_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())

@@ -218,20 +218,20 @@ void pool_bwd_seq(Seq& q, const float* S, const float* Z, int ldz, const float* 
 }
 
 void loss_fwd_seq(Seq& q, const float* ypred, const long long* label, const float* S, const float* adj,
-                  const int* num_nodes, float* loss_out, float* prob, float* dunit, int B, int C, int N, int K,
-                  int linkpred);
+                  const int* num_nodes, const float* norm, float* loss_out, float* prob, float* dunit, int B, int C,
+                  int N, int K, int linkpred);
 void loss_bwd_seq(Seq& q, const float* prob, const long long* label, const float* S, const float* adj,
-                  const int* num_nodes, const float* dloss, float* d_ypred, float* dS, int B, int C, int N, int K,
-                  int linkpred) {
+                  const int* num_nodes, const float* norm, const float* dloss, float* d_ypred, float* dS, int B, int C,
+                  int N, int K, int linkpred) {
     if (d_ypred) ce_bwd(q, prob, label, dloss, 1.f, d_ypred, B, C);
-    if (linkpred) linkpred_bwd(q, S, K, adj, num_nodes, dloss, dS, K, B, N, K, 0);
+    if (linkpred) linkpred_bwd(q, S, K, adj, num_nodes, dloss, dS, K, B, N, K, 0, norm);
 }
 
 __global__ void k_add2(float* out, const float* a, const float* b) { out[0] = a[0] + b[0]; out[1] = b[0]; }
 
 void loss_fwd_seq(Seq& q, const float* ypred, const long long* label, const float* S, const float* adj,
-                  const int* num_nodes, float* loss_out, float* prob, float* dunit, int B, int C, int N, int K,
-                  int linkpred) {
+                  const int* num_nodes, const float* norm, float* loss_out, float* prob, float* dunit, int B, int C,
+                  int N, int K, int linkpred) {
     float* tmp = q.alloc<float>(64);
     if (q.err) return;
     if (!linkpred) {                       // loss_out = (CE, 0): one launch
@@ -240,7 +240,7 @@ void loss_fwd_seq(Seq& q, const float* ypred, const long long* label, const floa
     }
     ce_fwd(q, ypred, label, tmp, prob, B, C, nullptr, dunit);
     if (linkpred) {
-        linkpred_fwd(q, S, K, adj, num_nodes, tmp + 1, B, N, K);
+        linkpred_fwd(q, S, K, adj, num_nodes, tmp + 1, B, N, K, norm);
         if (q.ok()) {
             hipLaunchKernelGGL(k_add2, dim3(1), dim3(1), 0, q.stream, loss_out, tmp, tmp + 1);
             q.check_launch("loss_add");
@@ -571,28 +571,28 @@ int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const fl
 }
 
 size_t dp_loss_workspace_bytes(int B, int N, int K, int linkpred) {
-    size_t f = sized([&](Seq& q) { loss_fwd_seq(q, 0, 0, 0, 0, 0, 0, 0, 0, B, 1, N, K, linkpred); });
-    size_t b = sized([&](Seq& q) { loss_bwd_seq(q, 0, 0, 0, 0, 0, 0, 0, 0, B, 1, N, K, linkpred); });
+    size_t f = sized([&](Seq& q) { loss_fwd_seq(q, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, 1, N, K, linkpred); });
+    size_t b = sized([&](Seq& q) { loss_bwd_seq(q, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, 1, N, K, linkpred); });
     return f > b ? f : b;
 }
 int dp_loss_forward(const float* ypred, const long long* label, const float* S, const float* adj, const int* num_nodes,
-                    float* loss_out, float* prob, float* d_ypred_unit, int B, int C, int N, int K, int linkpred,
-                    void* workspace, size_t workspace_bytes, void* stream) {
+                    const float* link_norm, float* loss_out, float* prob, float* d_ypred_unit, int B, int C, int N, int K,
+                    int linkpred, void* workspace, size_t workspace_bytes, void* stream) {
     NOTNULL(ypred); NOTNULL(label); NOTNULL(loss_out); NOTNULL(prob);
     NONNEG(B); NONNEG(C);
     DP_CHECK_ARG(!linkpred || (S && adj && N > 0 && K > 0), "linkpred needs S, adj, N, K");
     Seq q(STREAM(stream), workspace, workspace_bytes);
-    loss_fwd_seq(q, ypred, label, S, adj, num_nodes, loss_out, prob, d_ypred_unit, B, C, N, K, linkpred);
+    loss_fwd_seq(q, ypred, label, S, adj, num_nodes, link_norm, loss_out, prob, d_ypred_unit, B, C, N, K, linkpred);
     return q.err;
 }
 int dp_loss_backward(const float* prob, const long long* label, const float* S, const float* adj, const int* num_nodes,
-                     const float* dloss, float* d_ypred, float* dS, int B, int C, int N, int K, int linkpred,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+                     const float* link_norm, const float* dloss, float* d_ypred, float* dS, int B, int C, int N, int K,
+                     int linkpred, void* workspace, size_t workspace_bytes, void* stream) {
     NOTNULL(prob); NOTNULL(label);
     NONNEG(B); NONNEG(C);
     DP_CHECK_ARG(!linkpred || (S && adj && dS && N > 0 && K > 0), "linkpred needs S, adj, dS, N, K");
     Seq q(STREAM(stream), workspace, workspace_bytes);
-    loss_bwd_seq(q, prob, label, S, adj, num_nodes, dloss, d_ypred, dS, B, C, N, K, linkpred);
+    loss_bwd_seq(q, prob, label, S, adj, num_nodes, link_norm, dloss, d_ypred, dS, B, C, N, K, linkpred);
     return q.err;
 }
 

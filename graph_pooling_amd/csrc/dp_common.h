@@ -229,8 +229,10 @@ struct GroupCPtrs {
 void rownorm_fwd(Seq& q, const float* U, int ldu, const float* P /*add_self or null*/, GroupCPtrs bias,
                  RowGroups g, GroupPtrs yout, float* invn, float* part /*[rows,G,2] or null*/, long rows,
                  int normalize, int relu_stats);
-void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* part /*[B,n,G,2]; null: no BN*/, float* stats,
-                  RowGroups g, GroupPtrs xout, int B, int n, int relu);
+// Bs: number of graphs whose row partials `part` holds ([Bs, n, G, 2]); 0 = B.  Bs > B is sync-BN over several
+// data-parallel ranks: the statistics span every rank's batch, the rows normalised are this rank's B graphs.
+void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* part /*[Bs,n,G,2]; null: no BN*/, float* stats,
+                  RowGroups g, GroupPtrs xout, int B, int n, int relu, int Bs = 0);
 // apply_bn of one layer + the next layer's transform P = x W in one launch (row-local; small batches, widths <= 64)
 bool bn_transform_supported(RowGroups gin, RowGroups gout, int B);
 void bn_transform_fwd(Seq& q, const float* Y, int ldy, const float* part, float* stats, RowGroups gin, GroupPtrs xout,
@@ -242,7 +244,8 @@ void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat /*BN output, null when n
                  const float* invn, const float* stats, const float* part2, RowGroups g, float* dU, int ldu,
                  const GroupPtrs* dbias /*per group: bias-gradient slab of graph 0 (ld = distance between graphs);
                  column sums of dU are atomically added; null: none*/, int B, int n, int has_relu, int has_bn,
-                 int normalize, unsigned short* vs = nullptr /*also emit the 3-plane bf16 split of dU*/);
+                 int normalize, unsigned short* vs = nullptr /*also emit the 3-plane bf16 split of dU*/,
+                 int Bs = 0 /*graphs in part2 (sync-BN: B x ranks); 0 = B*/);
 int rownorm_bwd_chunks(int n);
 void colsum_batched(Seq& q, const float* X, int ldx, long strideX, int rows, int cols, float* out,
                     long strideOut, int batch, int rowsplit = 1);
@@ -372,8 +375,8 @@ void clip_adam_step(Seq& q, float* params, float* grads, float* exp_avg, float* 
 
 // (dp_linkpred.hip)
 void linkpred_fwd(Seq& q, const float* S, int lds, const float* adj, const int* num_nodes, float* loss_out,
-                  int B, int n, int K);
+                  int B, int n, int K, const float* norm = nullptr /*device scalar replacing sum n_b^2*/);
 void linkpred_bwd(Seq& q, const float* S, int lds, const float* adj, const int* num_nodes, const float* dloss,
-                  float* dS, int ldds, int B, int n, int K, int accumulate);
+                  float* dS, int ldds, int B, int n, int K, int accumulate, const float* norm = nullptr);
 
 }  // namespace dp

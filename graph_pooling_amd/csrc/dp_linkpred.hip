@@ -128,8 +128,11 @@ __global__ __launch_bounds__(256) void k_link_fwd(const float* S, int lds_ld, co
 }
 
 // loss = sum(partials) / sum_b n_b^2  (single block; deterministic);  also the backward scale dloss / sum n_b^2
+// norm (optional device scalar) replaces the local sum_b n_b^2: data-parallel ranks pass (global sum) / world so that
+// the mean of the per-rank losses and gradients equals the single-batch loss of encoders.py:1326,1331
 __global__ __launch_bounds__(256) void k_link_final(const float* partial, int count, const int* num_nodes, int B,
-                                                    int n, float* out, float* scale_out, const float* dloss) {
+                                                    int n, float* out, float* scale_out, const float* dloss,
+                                                    const float* norm) {
     __shared__ float red[4];
     float acc = 0.f;
     for (int i = threadIdx.x; i < count; i += 256) acc += partial ? partial[i] : 0.f;
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(256) void k_link_final(const float* partial, int co
             const double v = num_nodes ? (double)min(num_nodes[b], n) : (double)n;
             nn += v * v;
         }
+        if (norm) nn = (double)norm[0];
         if (out) out[0] = (float)((double)s / nn);
         if (scale_out) scale_out[0] = (float)((dloss ? (double)dloss[0] : 1.0) / nn);
     }
@@ -313,7 +317,7 @@ static void launch_link_fwd(Seq& q, const float* S, int lds_ld, const float* adj
 }
 
 void linkpred_fwd(Seq& q, const float* S, int lds_ld, const float* adj, const int* num_nodes, float* loss_out, int B,
-                  int n, int K) {
+                  int n, int K, const float* norm) {
     if (q.err) return;
     const int tiles = (n + 63) / 64;
     float* partial = q.alloc<float>((size_t)B * tiles * tiles);
@@ -330,7 +334,7 @@ void linkpred_fwd(Seq& q, const float* S, int lds_ld, const float* adj, const in
 #undef LK_FWD
     q.check_launch("link_fwd");
     hipLaunchKernelGGL(k_link_final, dim3(1), dim3(256), 0, q.stream, partial, B * tiles * tiles, num_nodes, B, n,
-                       loss_out, (float*)nullptr, (const float*)nullptr);
+                       loss_out, (float*)nullptr, (const float*)nullptr, norm);
     q.check_launch("link_final");
 }
 
@@ -350,7 +354,7 @@ static void launch_link_bwd(Seq& q, const float* S, int lds_ld, const float* adj
 }
 
 void linkpred_bwd(Seq& q, const float* S, int lds_ld, const float* adj, const int* num_nodes, const float* dloss,
-                  float* dS, int ldds, int B, int n, int K, int accumulate) {
+                  float* dS, int ldds, int B, int n, int K, int accumulate, const float* norm) {
     if (q.err) return;
     float* scale = q.alloc<float>(64);
     const int kt = lk_kt(K);
@@ -370,7 +374,7 @@ void linkpred_bwd(Seq& q, const float* S, int lds_ld, const float* adj, const in
         return;
     }
     hipLaunchKernelGGL(k_link_final, dim3(1), dim3(256), 0, q.stream, (const float*)nullptr, 0, num_nodes, B, n,
-                       (float*)nullptr, scale, dloss);
+                       (float*)nullptr, scale, dloss, norm);
     q.check_launch("link_scale");
 #define LK_BWD(T, J)                                                                                             \
     case T:                                                                                                      \

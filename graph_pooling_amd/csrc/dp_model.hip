@@ -189,6 +189,9 @@ int validate(const dp_encoder_cfg* c) {
         DP_CHECK_ARG(c->pred_dims[0] == feat, "pred_dims[0]=%d != readout width %d", c->pred_dims[0], feat);
     }
     DP_CHECK_ARG(c->n_graph_params >= 0 && c->n_graph_params <= c->n_params, "n_graph_params out of range");
+    DP_CHECK_ARG(c->bn_world >= 0 && c->bn_world <= 1024, "bn_world=%d out of range", c->bn_world);
+    DP_CHECK_ARG(c->bn_world <= 1 || c->exchange, "bn_world=%d needs the exchange callback", c->bn_world);
+    DP_CHECK_ARG(c->bn_world <= 1 || c->readout == 0, "sync-BN is implemented for the max-readout encoders");
     return DP_OK;
 }
 
@@ -245,6 +248,22 @@ BwdZero alloc_bwd_zero(Seq& q, const dp_encoder_cfg& c) {
     z.bar = q.alloc<int>(64 * (DP_MAX_LEVELS + 1));
     z.end = q.ws_off;
     return z;
+}
+
+// sync-BN (cfg.bn_world > 1): every BatchNorm site gathers its row partials from all ranks before combining them.
+// The one-workgroup-per-graph kernels and the whole-level kernels combine partials inside the launch, so they are
+// not used in this mode: all levels run on the generic per-layer kernels.
+inline int bn_world(const dp_encoder_cfg& c) { return c.bn_world > 1 ? c.bn_world : 1; }
+// local [B, n, G, 2] block -> gathered [world * B, n, G, 2]; returns the pointer the consumer should read
+const float* bn_exchange(Seq& q, const dp_encoder_cfg& c, const float* local, float* gathered, size_t floats) {
+    if (bn_world(c) == 1) return local;
+    if (!q.ok()) return gathered;
+    const int rc = c.exchange(c.exchange_user, local, gathered, floats * sizeof(float), (void*)q.stream);
+    if (rc != 0) {
+        set_error("sync-BN exchange callback failed (code %d)", rc);
+        q.err = DP_ERR_INVALID_ARG;
+    }
+    return gathered;
 }
 
 bool level_is_small(int B, const LevelInfo& li) {
@@ -359,16 +378,18 @@ void transform(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const Level
 
 void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
                    const float* params, float* Pj, float* Uj, float* part, float* part_b, const PackedAdj* pk,
-                   unsigned short* vs, float* lvl_part, int* bar /*zeroed in stream order, or null*/) {
+                   unsigned short* vs, float* lvl_part, int* bar /*zeroed in stream order, or null*/,
+                   float* part_all /*[world * B, n, G, 2] under sync-BN*/) {
     const int B = c.B, n = li.n;
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
-    if (bar && level_is_fused(c, li, io, true)) {
+    const int W = bn_world(c);
+    if (W == 1 && bar && level_is_fused(c, li, io, true)) {
         small_level_fwd(q, small_level_io(li, lv, io, params, lvl_part, bar), B, n, li.e->dims, li.L, add_self ? 1 : 0,
                         bn ? 1 : 0);
         return;
     }
-    if (level_is_small(B, li) && !level_has_dropout(li, io)) {
+    if (W == 1 && level_is_small(B, li) && !level_has_dropout(li, io)) {
         // pooled level (or tiny graphs): one launch per layer, one workgroup per graph (dp_small.hip)
         float* pbuf[2] = {part, part_b};
         for (int l = 0; l < li.L; ++l) {
@@ -436,7 +457,8 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
             xout.ld[1] = li.Da;
             // apply_bn and the NEXT layer's transform in one launch when that transform is a plain row-local product
             const RowGroups gnext = groups_of(li, l + 1);
-            bool plain_next = !knobs().no_level_fusion && bn_transform_supported(g, gnext, B);
+            const float* part_r = bn ? bn_exchange(q, c, part, part_all, (size_t)B * n * li.G * 2) : nullptr;
+            bool plain_next = W == 1 && !knobs().no_level_fusion && bn_transform_supported(g, gnext, B);
             for (int gi = 0; gi < li.G; ++gi) plain_next = plain_next && !drop_mask(li, io, gi, l + 1);
             if (plain_next) {
                 const float* Wn[2] = {PW(params, li.e->w_off[l + 1]), li.a ? PW(params, li.a->w_off[l + 1]) : nullptr};
@@ -446,7 +468,7 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
                                  ctn, B, n, 1, presplit_n ? vs : nullptr);
                 transformed = true;
             } else {
-                bn_apply_fwd(q, lv.layer[l].Y, ct, bn ? part : nullptr, lv.layer[l].stats, g, xout, B, n, 1);
+                bn_apply_fwd(q, lv.layer[l].Y, ct, part_r, lv.layer[l].stats, g, xout, B, n, 1, B * W);
             }
         }
     }
@@ -455,18 +477,19 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
 void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const LevelSave& lv, const LevelIO& io,
                     const float* params, const LevelGrad& gr, float* slabs, long slab_stride, int KS, float* Pj,
                     float* dUj, float* Gj, float* part, float* part_b, const PackedAdj* pk, unsigned short* vs,
-                    float* const dxm[2], float* lvl_part, int* bar) {
+                    float* const dxm[2], float* lvl_part, int* bar, float* part_all) {
     const int B = c.B, n = li.n;
+    const int W = bn_world(c);
     const long gstride = slab_stride * KS;     // slab rows of one graph: KS split-K partials
     const int ks_level = n >= 256 ? KS : 1;
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
-    if (lvl_part && bar && level_is_fused(c, li, io, true)) {
+    if (W == 1 && lvl_part && bar && level_is_fused(c, li, io, true)) {
         small_level_bwd(q, small_level_io(li, lv, io, params, lvl_part, bar), gr.dZe, gr.dX0, gr.dAdj, slabs, gstride,
                         B, n, li.e->dims, li.L, add_self ? 1 : 0, bn ? 1 : 0);
         return;
     }
-    if (level_is_small(B, li) && !level_has_dropout(li, io)) {
+    if (W == 1 && level_is_small(B, li) && !level_has_dropout(li, io)) {
         float* pbuf[2] = {part, part_b};
         for (int l = li.L - 1; l >= 0; --l) {
             const bool last = l == li.L - 1;
@@ -510,15 +533,19 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
             y.ld[1] = ct;
         }
         const bool has_bn = !last && bn;
-        if (has_bn) bn_bwd_partials(q, dx, xhat, g, part, (long)B * n);
+        const float* part2 = part;
+        if (has_bn) {
+            bn_bwd_partials(q, dx, xhat, g, part, (long)B * n);
+            part2 = bn_exchange(q, c, part, part_all, (size_t)B * n * li.G * 2);
+        }
         // bias gradients: column sums of dU go straight into each graph's (zeroed) slab row with float atomics
         GroupPtrs dbias{};
         dbias.p[0] = li.e->b_off[l] >= 0 ? slabs + li.e->b_off[l] : nullptr;
         dbias.p[1] = (li.a && li.a->b_off[l] >= 0) ? slabs + li.a->b_off[l] : nullptr;
         dbias.ld[0] = dbias.ld[1] = (int)gstride;
         const bool presplit = pk && vs && aggregate_packed_usable(io.adj, n, ct);
-        rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, part, g, dUj, ct, &dbias, B, n, !last, has_bn,
-                    1, presplit ? vs : nullptr);
+        rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, part2, g, dUj, ct, &dbias, B, n, !last, has_bn,
+                    1, presplit ? vs : nullptr, B * W);
         // G = A^T dU (+ dU)
         aggregate(q, io.adj, dUj, ct, Gj, ct, B, n, ct, true, 0.f, pk, vs, presplit);
         if (add_self) axpy(q, Gj, dUj, 1.f, (long)B * n * ct);
@@ -612,7 +639,7 @@ size_t dropout_scratch_floats(const dp_encoder_cfg& c) {
 
 struct Scratch {
     float* xm[2];
-    float *Pj, *Uj, *part, *part_b, *logits, *lvl_part;
+    float *Pj, *Uj, *part, *part_b, *logits, *lvl_part, *part_all;
     unsigned short* vs;      // 3-plane bf16 split of the current V operand (level 0, packed adjacency)
 };
 size_t vs_elems(const dp_encoder_cfg& c) {
@@ -665,6 +692,7 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
     s.part_b = q.alloc<float>(maxPart);
     s.logits = q.alloc<float>(maxLog > 0 ? maxLog : 1);
     s.lvl_part = q.alloc<float>(level_part_floats(c));
+    s.part_all = bn_world(c) > 1 ? q.alloc<float>(maxPart * bn_world(c)) : nullptr;
     s.vs = q.alloc<unsigned short>(vs_elems(c));
     const size_t dsf = dropout_scratch_floats(c);
     s.xm[0] = dsf ? q.alloc<float>(dsf) : nullptr;
@@ -718,7 +746,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
         io.xm[1] = sc.xm[1];
         io.pack = (j == 0 && pack_in_level) ? &pack : nullptr;
         level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part, sc.part_b, j == 0 ? pkp : nullptr, sc.vs,
-                      sc.lvl_part, level_bar);
+                      sc.lvl_part, level_bar, sc.part_all);
         level_bar = nullptr;
         const int* nn_j = (j == 0) ? num_nodes : nullptr;
         if (c.readout == 0) {
@@ -823,6 +851,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     float* part = q.alloc<float>(maxPart);
     float* part_b = q.alloc<float>(maxPart);
     float* lvl_part = q.alloc<float>(level_part_floats(c));
+    float* part_all = bn_world(c) > 1 ? q.alloc<float>(maxPart * bn_world(c)) : nullptr;
     unsigned short* vs = q.alloc<unsigned short>(vs_elems(c));
     float* dS = q.alloc<float>(maxSK ? maxSK : 1);
     float* dlog = q.alloc<float>(maxSK ? maxSK : 1);
@@ -969,7 +998,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
             }
         }
         level_backward(q, c, li, lv, io, params, gr[j], slabs, slab_stride, KS, Pj, dUj, Gj, part, part_b,
-                       j == 0 ? pkp : nullptr, vs, dxm, lvl_part, bz.bar + 64 * j);
+                       j == 0 ? pkp : nullptr, vs, dxm, lvl_part, bz.bar + 64 * j, part_all);
     }
     reduce_slabs(q, slabs, slab_stride, B * KS, grads, c.n_graph_params, 0);
     return q.err;

@@ -116,6 +116,7 @@ struct BnApplyArgs {
     int B, n;
     int relu;
     int stats_ready;     // big batches: (mu, rstd) were finalised by k_bn_finalize, read them instead of combining
+    int Bs;              // graphs the statistics span = partial blocks in `part` (B, or B x ranks under sync-BN)
 };
 // big batches: one team per (node, group) combines the B partials once (the apply kernel would otherwise repeat
 // that B-term reduction in every one of the B rows of the node)
@@ -128,14 +129,14 @@ __global__ __launch_bounds__(256) void k_bn_finalize(BnApplyArgs a) {
     const long pstride = (long)a.n * a.g.G * 2;
     const float* p = a.part + it * 2;
     float sm = 0.f;
-    for (int b = tl; b < a.B; b += 16) sm += p[b * pstride];
-    const float mu = team_sum(sm) / (float)a.B;
+    for (int b = tl; b < a.Bs; b += 16) sm += p[b * pstride];
+    const float mu = team_sum(sm) / (float)a.Bs;
     float s2 = 0.f;
-    for (int b = tl; b < a.B; b += 16) {
+    for (int b = tl; b < a.Bs; b += 16) {
         const float d = p[b * pstride] - mu;
         s2 += p[b * pstride + 1] + (float)w * d * d;
     }
-    const float var = team_sum(s2) / ((float)a.B * (float)w);
+    const float var = team_sum(s2) / ((float)a.Bs * (float)w);
     if (tl == 0) {
         a.stats[it * 2] = mu;
         a.stats[it * 2 + 1] = 1.0f / sqrtf(var + BN_EPS);
@@ -171,21 +172,21 @@ __global__ __launch_bounds__(256) void k_bn_apply_fwd(BnApplyArgs a) {
             float pm[2], pq[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const long o = (long)min(tl + 16 * u, a.B - 1) * pstride;
+                const long o = (long)min(tl + 16 * u, a.Bs - 1) * pstride;
                 pm[u] = p[o];
                 pq[u] = p[o + 1];
             }
             float sm = 0.f;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) sm += (tl + 16 * u < a.B) ? pm[u] : 0.f;
-            mu = team_sum(sm) / (float)a.B;
+            for (int u = 0; u < 2; ++u) sm += (tl + 16 * u < a.Bs) ? pm[u] : 0.f;
+            mu = team_sum(sm) / (float)a.Bs;
             float s2 = 0.f;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const float d = pm[u] - mu;
-                s2 += (tl + 16 * u < a.B) ? pq[u] + (float)w * d * d : 0.f;
+                s2 += (tl + 16 * u < a.Bs) ? pq[u] + (float)w * d * d : 0.f;
             }
-            const float var = team_sum(s2) / ((float)a.B * (float)w);
+            const float var = team_sum(s2) / ((float)a.Bs * (float)w);
             rstd = 1.0f / sqrtf(var + BN_EPS);
             if (row < a.n && tl == 0) {   // the b == 0 row of this node
                 a.stats[((long)node * a.g.G + g) * 2] = mu;
@@ -209,10 +210,11 @@ __global__ __launch_bounds__(256) void k_bn_apply_fwd(BnApplyArgs a) {
     }
 }
 void bn_apply_fwd(Seq& q, const float* Y, int ldy, const float* part, float* stats, RowGroups g, GroupPtrs xout,
-                  int B, int n, int relu) {
+                  int B, int n, int relu, int Bs) {
     if (!q.ok()) return;
-    BnApplyArgs a{Y, ldy, part, stats, g, xout, B, n, relu, 0};
-    if (part && B > 32) {
+    if (Bs <= 0) Bs = B;
+    BnApplyArgs a{Y, ldy, part, stats, g, xout, B, n, relu, 0, Bs};
+    if (part && Bs > 32) {
         hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)(((long)n * g.G + 15) / 16)), dim3(256), 0, q.stream, a);
         q.check_launch("bn_finalize");
         a.stats_ready = 1;
@@ -381,7 +383,7 @@ void bn_transform_fwd(Seq& q, const float* Y, int ldy, const float* part, float*
                       unsigned short* vs) {
     if (!q.ok()) return;
     BnTransformArgs t{};
-    t.bn = BnApplyArgs{Y, ldy, part, stats, gin, xout, B, n, relu, 0};
+    t.bn = BnApplyArgs{Y, ldy, part, stats, gin, xout, B, n, relu, 0, B};
     t.W[0] = W[0];
     t.W[1] = W[1];
     t.gout = gout;
@@ -461,6 +463,7 @@ struct RownormBwdArgs {
     int B, n;
     int rows_per_chunk;
     int has_relu, has_bn, normalize;
+    int Bs;               // graphs in part2 (B, or B x ranks under sync-BN)
 };
 // grid (chunks, B): a workgroup owns a contiguous chunk of rows of ONE graph, so the column sums of dU
 // (the bias gradients, db = sum_rows dU) can be accumulated in LDS and leave as one partial per workgroup.
@@ -508,14 +511,14 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
             {
                 const long pstride = (long)a.n * a.g.G * 2;
                 const float* p = (a.has_bn ? a.part2 : dx) + (a.has_bn ? ((long)node * a.g.G + g) * 2 : 0);
-                const int nb = a.has_bn ? a.B : 0;
+                const int nb = a.has_bn ? a.Bs : 0;
                 for (int bb = tl; bb < nb; bb += 16) {
                     s0 += p[bb * pstride];
                     s1 += p[bb * pstride + 1];
                 }
             }
             // ---- arithmetic
-            const float cnt = (float)a.B * (float)w;
+            const float cnt = (float)a.Bs * (float)w;
             const float rstd = a.has_bn ? rstd_l : 1.f;
             const float m0 = a.has_bn ? team_sum(s0) / cnt : 0.f;
             const float m1 = a.has_bn ? team_sum(s1) / cnt : 0.f;
@@ -552,11 +555,11 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
             const long pstride = (long)a.n * a.g.G * 2;
             const float* p = a.part2 + ((long)node * a.g.G + g) * 2;
             float s0 = 0.f, s1 = 0.f;
-            for (int bb = tl; bb < a.B; bb += 16) {
+            for (int bb = tl; bb < a.Bs; bb += 16) {
                 s0 += p[bb * pstride];
                 s1 += p[bb * pstride + 1];
             }
-            const float cnt = (float)a.B * (float)w;
+            const float cnt = (float)a.Bs * (float)w;
             m0 = team_sum(s0) / cnt;
             m1 = team_sum(s1) / cnt;
         }
@@ -621,8 +624,9 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
 int rownorm_bwd_chunks(int n) { return (n + 7) / 8; }
 void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const float* invn, const float* stats,
                  const float* part2, RowGroups g, float* dU, int ldu, const GroupPtrs* dbias, int B, int n,
-                 int has_relu, int has_bn, int normalize, unsigned short* vs) {
+                 int has_relu, int has_bn, int normalize, unsigned short* vs, int Bs) {
     if (!q.ok()) return;
+    if (Bs <= 0) Bs = B;
     GroupPtrs db{};
     int want = 0;
     if (dbias) {
@@ -631,7 +635,7 @@ void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const flo
     }
     const int ct = g.c0[g.G - 1] + g.w[g.G - 1];
     RownormBwdArgs a{dx, xhat, y, invn, stats, part2, g, dU, ldu, db, want, vs, (ct + 15) / 16, ((n + 31) / 32) * 4,
-                     B, n, 8, has_relu, has_bn, normalize};
+                     B, n, 8, has_relu, has_bn, normalize, Bs};
     const int maxw = g.G == 2 && g.w[1] > g.w[0] ? g.w[1] : g.w[0];
     const dim3 grid(rownorm_bwd_chunks(n), B);
     const size_t lds = ((want ? 16 : 0) + (vs ? 8 : 0)) * ct * sizeof(float);

@@ -184,6 +184,25 @@ class _Plan:
     def __init__(self, owner, B, N, device):
         lib = _lib.load()
         self.cfg = owner._build_cfg(B, N)
+        self._exchange_cb = None
+        sync = getattr(owner, "_sync_bn", None)
+        if sync is not None and sync.world > 1:
+            # sync-BN: the library calls back between the launch that writes a BatchNorm site's local row partials
+            # and the launch that combines them; both blocks live inside this plan's workspace
+            def exchange(_user, local, gathered, nbytes, _stream, plan=self, sync=sync):
+                try:
+                    base = plan.workspace.data_ptr()
+                    lo, go = local - base, gathered - base
+                    src = plan.workspace[lo:lo + nbytes].view(torch.float32)
+                    dst = plan.workspace[go:go + nbytes * sync.world].view(torch.float32)
+                    sync.all_gather(dst, src)
+                    return 0
+                except Exception as e:      # noqa: BLE001 — never let an exception unwind through the C frames
+                    sync.error = e
+                    return 1
+            self._exchange_cb = _lib.EXCHANGE_FN(exchange)
+            self.cfg.bn_world = sync.world
+            self.cfg.exchange = C.cast(self._exchange_cb, C.c_void_p)
         self.drop_segments, self.drop_total = owner._fill_dropout(self.cfg, B)
         self.label_dim = owner.label_dim
         self.save_bytes = lib.dp_encoder_save_bytes(C.byref(self.cfg))
@@ -535,7 +554,7 @@ class _Loss(torch.Tensor):
 
 class _LossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, label, S, adj, num_nodes, linkpred):
+    def forward(ctx, pred, label, S, adj, num_nodes, linkpred, link_norm=None):
         lib = _lib.load()
         _lib.require_gpu_tensor(pred, "pred")
         pred = pred.contiguous().float()
@@ -553,9 +572,11 @@ class _LossFn(torch.autograd.Function):
         dunit = torch.empty(B, Cc, device=pred.device, dtype=torch.float32)
         _lib.check(lib.dp_loss_forward(pred.data_ptr(), label.data_ptr(), _lib.ptr(S) if linkpred else None,
                                        _lib.ptr(adj) if linkpred else None, _lib.ptr(num_nodes),
+                                       _lib.ptr(link_norm) if linkpred else None,
                                        out.data_ptr(), prob.data_ptr(), dunit.data_ptr(), B, Cc, N, K, int(linkpred),
                                        ws.data_ptr(), wsb, _lib.current_stream()), "dp_loss_forward")
         ctx.saved = (prob, dunit, label, S if linkpred else None, adj if linkpred else None, num_nodes, ws)
+        ctx.link_norm = link_norm if linkpred else None
         ctx.dims = (B, Cc, N, K, bool(linkpred))
         total, link = out[0], out[1]
         ctx.mark_non_differentiable(link)
@@ -568,25 +589,34 @@ class _LossFn(torch.autograd.Function):
         prob, dunit, label, S, adj, num_nodes, ws = ctx.saved
         B, Cc, N, K, linkpred = ctx.dims
         if dtotal is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         seed = _UNIT_SEED.get(dtotal.device)
         unit = seed is not None and dtotal.data_ptr() == seed.data_ptr() and dtotal.dim() == 0
         if unit and not linkpred:
-            return dunit, None, None, None, None, None     # written by the loss kernel: nothing to launch
+            return dunit, None, None, None, None, None, None     # written by the loss kernel: nothing to launch
         dtotal = dtotal.contiguous().float()
         dpred = dunit if unit else torch.empty(B, Cc, device=prob.device, dtype=torch.float32)
         dS = torch.empty_like(S) if linkpred else None
         _lib.check(lib.dp_loss_backward(prob.data_ptr(), label.data_ptr(), _lib.ptr(S), _lib.ptr(adj),
-                                        _lib.ptr(num_nodes), None if unit else dtotal.data_ptr(),
+                                        _lib.ptr(num_nodes), _lib.ptr(ctx.link_norm),
+                                        None if unit else dtotal.data_ptr(),
                                         None if unit else dpred.data_ptr(), _lib.ptr(dS),
                                         B, Cc, N, K, int(linkpred), ws.data_ptr(), ws.numel(),
                                         _lib.current_stream()), "dp_loss_backward")
-        return dpred, None, dS, None, None, None
+        return dpred, None, dS, None, None, None, None
 
 
 def _loss(owner, pred, label, S, adj, batch_num_nodes, linkpred):
     nn_dev = _num_nodes_device(batch_num_nodes, pred.device) if linkpred else None
-    total, link = _LossFn.apply(pred, label, S, adj, nn_dev, linkpred)
+    link_norm = None
+    sync = getattr(owner, "_sync_bn", None)
+    if linkpred and sync is not None and sync.world > 1:
+        # the link loss divides by sum_b n_b^2 over the WHOLE batch (encoders.py:1326,1331): every rank uses
+        # (global sum) / world, so the mean over ranks of the per-rank terms is the single-batch loss
+        n_eff = nn_dev.clamp(max=S.shape[1]).float() if nn_dev is not None else \
+            torch.full((S.shape[0],), float(S.shape[1]), device=pred.device)
+        link_norm = sync.all_reduce_sum((n_eff * n_eff).sum().reshape(1)) / float(sync.world)
+    total, link = _LossFn.apply(pred, label, S, adj, nn_dev, linkpred, link_norm)
     if linkpred:
         owner.link_loss = link
     _unit_seed(pred.device)                   # make sure the cached seed exists before anyone captures a graph

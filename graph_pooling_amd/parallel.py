@@ -7,9 +7,15 @@ bucket and ONE collective (`torch.distributed` backend "nccl" = RCCL on ROCm; "g
 there is nothing to overlap it with.  The reference has no distributed code at all (train.py:624 picks
 a single device).
 
-BatchNorm caveat: apply_bn normalises per node index over the LOCAL batch
-(encoders.py:1048-1052), so a sharded step equals "world_size independent reference steps with
-averaged gradients", not one step on the concatenated batch.
+BatchNorm: apply_bn normalises per node index over the whole batch
+(encoders.py:1048-1052).  Two modes:
+  * local (default, throughput): statistics over the rank's shard — a sharded step equals "world_size
+    independent reference steps with averaged gradients", not one step on the concatenated batch;
+  * sync_bn=True (parity): every BatchNorm site all-gathers its per-row partials (mean, M2 forward;
+    sum dx, sum dx*xhat backward: [B, n, G, 2] floats, 80 KB at the DD shape) before combining them, and the
+    link loss is normalised by the global sum of n_b^2 — the averaged gradients are then those of ONE
+    reference step on the concatenated batch (checked against the oracle on the GPU box with two ranks,
+    tests/test_gpu_parallel.py).  Costs 2 (L-1) (1 + 2P) extra small collectives per step.
 """
 from __future__ import annotations
 
@@ -26,12 +32,25 @@ class DataParallelEncoder:
         loss.backward(); dp.reduce_gradients(); clip_grad_norm_(...); optimizer.step()
     """
 
-    def __init__(self, model, process_group: Optional[dist.ProcessGroup] = None, broadcast: bool = True):
+    def __init__(self, model, process_group: Optional[dist.ProcessGroup] = None, broadcast: bool = True,
+                 sync_bn: bool = False):
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # How the mean over ranks is formed is decided ONCE, here, identically on every rank: RCCL averages inside
+        # the all-reduce (ncclAvg), gloo (CPU tests, one-GPU rehearsals) has no AVG -> SUM, then one scale.  A failing
+        # collective is never caught and retried: it propagates and the process exits non-zero.
+        self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        self.reduce_op = dist.ReduceOp.AVG if self.backend == "nccl" else dist.ReduceOp.SUM
+        if dist.is_initialized() and dist.get_rank(process_group) == 0:
+            print(f"[graph_pooling_amd.parallel] world {self.world}, backend {self.backend}: gradients averaged with "
+                  f"{'AVG inside the all-reduce' if self.backend == 'nccl' else 'SUM + scale'}; "
+                  f"BatchNorm statistics {'synchronised' if sync_bn else 'local to a rank'}", flush=True)
         device = next(model.parameters()).device
         model._ensure_flat(device)
+        if sync_bn and self.world > 1:
+            model._sync_bn = SyncBatchNormExchange(process_group, self.world)
+            model._plans = {}                       # plans built before carry no exchange callback
         if broadcast and self.world > 1:
             self.sync_parameters()
 
@@ -48,18 +67,10 @@ class DataParallelEncoder:
         dist.broadcast(m._flat, src=src, group=self.group)
 
     def _average(self, flat):
-        """Mean over ranks in place: ONE collective.  RCCL averages inside the all-reduce (ncclAvg); gloo (CPU tests)
-        has no AVG, so sum and scale."""
-        if getattr(self, "_use_avg", None) is None:
-            self._use_avg = dist.get_backend(self.group) == "nccl"
-        if self._use_avg:
-            try:
-                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
-                return
-            except (RuntimeError, ValueError):      # a collective library without ncclAvg: sum and scale instead
-                self._use_avg = False
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.div_(self.world)
+        """Mean over ranks in place: ONE collective (mode fixed in __init__; errors propagate)."""
+        dist.all_reduce(flat, op=self.reduce_op, group=self.group)
+        if self.reduce_op != dist.ReduceOp.AVG:
+            flat.div_(self.world)
 
     def _aliased_flat_grad(self):
         m = self.model
@@ -93,6 +104,28 @@ class DataParallelEncoder:
                 p.grad = flat[off:off + numel].view(shape)
             else:
                 p.grad.copy_(flat[off:off + numel].view(shape))
+
+
+class SyncBatchNormExchange:
+    """The collectives of sync-BN mode, called from inside dp_encoder_forward / backward through the plan's exchange
+    callback (encoders._Plan): an all-gather of a BatchNorm site's row partials on the current stream."""
+
+    def __init__(self, group, world):
+        self.group, self.world = group, world
+        self.error = None
+        self.calls = 0
+
+    def all_gather(self, dst, src):
+        # rank-major = batch-major: rank r's block lands at rows [r * B, (r + 1) * B) of the gathered partials
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(dst, src, group=self.group)
+        else:
+            dist.all_gather(list(dst.chunk(self.world)), src, group=self.group)
+        self.calls += 1
+
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
 
 
 def shard_batch(batch: dict, rank: int, world: int) -> dict:

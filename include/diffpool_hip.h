@@ -204,6 +204,14 @@ typedef struct {
                                         Layer 0 (conv_first) has none in the reference; must be -1. */
 } dp_stack_cfg;
 
+/* Sync-BN exchange (data parallelism, SURVEY 8(e) mode ii).  apply_bn couples the whole batch (encoders.py:1048-1052);
+ * when a batch is sharded over `bn_world` ranks the per-row partials every BatchNorm site produces must be gathered
+ * from all ranks before they are combined.  The library calls `exchange` from inside dp_encoder_forward / backward,
+ * between the launch that writes the local block and the launch that reads the gathered one; the callback must
+ * ENQUEUE, on `stream`, an all-gather of `bytes_per_rank` bytes at `local` into `gathered` (rank-major,
+ * bn_world * bytes_per_rank bytes; both are device pointers inside the call's workspace) and return 0. */
+typedef int (*dp_exchange_fn)(void* user, const void* local, void* gathered, size_t bytes_per_rank, void* stream);
+
 typedef struct {
     int B, N;                        /* batch, padded node count */
     int num_pooling;                 /* P */
@@ -226,6 +234,10 @@ typedef struct {
     long n_graph_params;             /* params [0, n_graph_params) are the GCN stacks + assign heads
                                         (their gradients are reduced from per-graph slabs); the
                                         pred_model / Set2Set parameters follow */
+    int bn_world;                    /* 0 / 1: apply_bn over the local batch; W > 1: over the W equal shards of a
+                                        data-parallel batch (every rank passes the same B) through `exchange` */
+    dp_exchange_fn exchange;
+    void* exchange_user;
 } dp_encoder_cfg;
 
 size_t dp_sizeof_encoder_cfg(void); /* sizeof(dp_encoder_cfg): lets a binding check its struct layout */
@@ -277,14 +289,17 @@ int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const fl
  * the same launch — `loss.backward()` (train.py:208) sends exactly that down, so the caller can hand it to
  * dp_encoder_backward without a gradient launch of its own. */
 size_t dp_loss_workspace_bytes(int B, int N, int K, int linkpred);
+/* link_norm (device scalar or NULL): replaces the link loss's normaliser sum_b n_b^2 (encoders.py:1326,1331).  Under
+ * data parallelism every rank passes (sum over ALL ranks' graphs) / world_size, so that the mean over ranks of the
+ * per-rank losses and gradients is the loss of the concatenated batch. */
 int dp_loss_forward(const float* ypred, const long long* label, const float* S, const float* adj,
-                    const int* num_nodes, float* loss_out, float* prob, float* d_ypred_unit, int B, int C, int N,
-                    int K, int linkpred, void* workspace, size_t workspace_bytes, void* stream);
+                    const int* num_nodes, const float* link_norm, float* loss_out, float* prob, float* d_ypred_unit,
+                    int B, int C, int N, int K, int linkpred, void* workspace, size_t workspace_bytes, void* stream);
 /* dloss: device scalar (NULL = 1).  d_ypred [B,C] (NULL: not wanted — the caller uses d_ypred_unit), dS [B,N,K]
  * (only when linkpred) overwritten. */
 int dp_loss_backward(const float* prob, const long long* label, const float* S, const float* adj,
-                     const int* num_nodes, const float* dloss, float* d_ypred, float* dS, int B, int C,
-                     int N, int K, int linkpred, void* workspace, size_t workspace_bytes, void* stream);
+                     const int* num_nodes, const float* link_norm, const float* dloss, float* d_ypred, float* dS,
+                     int B, int C, int N, int K, int linkpred, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ N1  on-device batch builder
  * Replaces GraphSampler.__getitem__ + collate + H2D of the dense batch (graph_sampler.py:97-109, train.py:197-201):

@@ -1,6 +1,6 @@
-"""N > 1 path on CPU: two `gloo` ranks exercise the data-parallel wrapper (flat parameter broadcast and
-the single flat-gradient all-reduce) without any GPU.  The kernels are not involved — gradients are
-injected — so this checks the collective plumbing bench.py / train loops rely on."""
+"""N > 1 path on CPU: two `gloo` ranks exercise the data-parallel wrapper (flat parameter broadcast, the single
+flat-gradient all-reduce with gradients from the oracle's backward on each shard, and the sync-BN partial exchange)
+without any GPU.  The HIP kernels meet the collectives in tests/test_gpu_parallel.py (two ranks on the GPU box)."""
 import os
 import socket
 
@@ -71,6 +71,74 @@ def test_two_rank_gloo_flat_gradient_allreduce():
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for res in results:
+        assert all(res[1:]), res
+
+
+def _oracle_worker(rank, world, port, q):
+    """Each rank's gradients come from the ORACLE's backward on its shard (the kernels need a GPU); after the
+    wrapper's all-reduce they must equal the mean of the per-shard oracle gradients, which every rank also computes
+    directly.  Then the sync-BN exchange: per-row BatchNorm partials of each shard, all-gathered through
+    SyncBatchNormExchange and Chan-combined, must reproduce apply_bn over the concatenated batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graph_pooling_amd.encoders import SoftPoolingGcnEncoder
+        from graph_pooling_amd.parallel import DataParallelEncoder, SyncBatchNormExchange
+        from oracle import diffpool_oracle as O
+        Bl, N, F_, H, Cc = 3, 16, 3, 8, 2
+        x, adj, nn_, label = O.make_batch(Bl * world, N, F_, n_min=2, p=0.3, seed=9, n_classes=Cc)
+        model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, 3, H, assign_ratio=0.25, linkpred=True)
+        params = O.init_params({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=3, bias_scale=0.1)
+        model.load_state_dict(params)
+        dp = DataParallelEncoder(model)
+
+        def shard_grads(r):
+            sl = slice(r * Bl, (r + 1) * Bl)
+            P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+            y, inter = O.softpool_forward(P, x[sl], adj[sl], nn_[sl], x[sl])
+            loss, _ = O.softpool_loss(y, label[sl], inter["assign_0"], adj[sl], nn_[sl], True)
+            loss.backward()
+            return {k: v.grad for k, v in P.items()}
+        mine = shard_grads(rank)
+        for k, p_ in model.named_parameters():
+            p_.grad = mine[k].clone()
+        dp.reduce_gradients()
+        every = [shard_grads(r) for r in range(world)]
+        mean_ok = all(torch.allclose(p_.grad, sum(g[k] for g in every) / world, rtol=1e-6, atol=1e-8)
+                      for k, p_ in model.named_parameters())
+
+        # sync-BN exchange: local (row mean, row M2) partials -> gathered, batch-major -> Chan combine
+        ex = SyncBatchNormExchange(None, world)
+        g = torch.Generator().manual_seed(4)
+        act = torch.randn(Bl * world, N, 7, generator=g)
+        loc = act[rank * Bl:(rank + 1) * Bl]
+        mean = loc.mean(dim=2)
+        part = torch.stack([mean, ((loc - mean.unsqueeze(2)) ** 2).sum(dim=2)], dim=2).contiguous()     # [Bl, N, 2]
+        allp = torch.empty(world * Bl, N, 2)
+        ex.all_gather(allp, part)
+        mu = allp[:, :, 0].mean(dim=0)
+        var = (allp[:, :, 1] + 7 * (allp[:, :, 0] - mu) ** 2).sum(dim=0) / (world * Bl * 7)
+        mine_bn = (loc - mu.view(1, N, 1)) / torch.sqrt(var.view(1, N, 1) + 1e-5)
+        bn_ok = torch.allclose(mine_bn, O.bn_node(act)[rank * Bl:(rank + 1) * Bl], rtol=1e-5, atol=1e-6)
+        q.put((rank, mean_ok, bn_ok, ex.calls == 1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_oracle_gradients_and_sync_bn_exchange():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_oracle_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
