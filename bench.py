@@ -297,6 +297,45 @@ def mfma_probe(w, device, iters=50):
                 mfma_busy_pmc=pmc)
 
 
+def _collective_capture_works(dist, device, world, rank):
+    """Capture and replay one all-reduce on a throw-away communicator; True iff it ran and gave the right sum on
+    every rank."""
+    ok = 0.0
+    try:
+        grp = dist.new_group(ranks=list(range(world)), backend="nccl")
+        t = torch.full((1024,), float(rank + 1), device=device)
+        dist.all_reduce(t, group=grp)                       # communicator set-up happens eagerly
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            t.fill_(float(rank + 1))
+            dist.all_reduce(t, group=grp)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        t.fill_(float(rank + 1))
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            dist.all_reduce(t, group=grp)
+        t.fill_(float(rank + 1))
+        g.replay()
+        torch.cuda.synchronize()
+        ok = 1.0 if abs(float(t[0]) - world * (world + 1) / 2) < 1e-3 else 0.0
+    except Exception as e:                                   # noqa: BLE001
+        print(f"[bench] rank {rank}: a captured all-reduce is not available here ({type(e).__name__}: {e})",
+              file=sys.stderr)
+        ok = 0.0
+        try:
+            torch.cuda.synchronize()
+        except Exception:                                    # noqa: BLE001
+            pass
+    # every rank must take the same path
+    flag = torch.tensor([ok], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() > 0.5)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,6 +345,9 @@ def main():
     ap.add_argument("--linkpred", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N > 1: BatchNorm statistics and the link-loss normaliser span all ranks (parity mode: the step "
+                         "equals one reference step on the concatenated batch); default is local statistics")
     ap.add_argument("--eval", action="store_true",
                     help="time the forward-only evaluation step (model.predict: DP_MODE_EVAL forward + on-device arg-max, "
                          "train.py:30-58) instead of forward + loss + backward")
@@ -347,7 +389,17 @@ def main():
     dp = None
     if world > 1:
         from graph_pooling_amd.parallel import DataParallelEncoder
-        dp = DataParallelEncoder(model)
+        dp = DataParallelEncoder(model, sync_bn=args.sync_bn)
+    # N > 1 on RCCL: the flat-gradient all-reduce is captured INTO the step's hipGraph (torch.distributed's NCCL
+    # collectives are capturable), so a step stays one graph launch.  Whether this runtime can capture a collective
+    # is tried first on a throw-away communicator: a failed capture can leave a communicator unusable, and the real
+    # one must survive to run the collective eagerly instead.  DP_BENCH_GRAPH_ALLREDUCE=0 skips the attempt.
+    graph_allreduce = False
+    if dp is not None and not rehearse and not args.no_graph and os.environ.get("DP_BENCH_GRAPH_ALLREDUCE", "1") != "0":
+        graph_allreduce = _collective_capture_works(dist, device, world, rank)
+        if rank == 0:
+            print(f"[bench] gradient all-reduce {'inside' if graph_allreduce else 'outside'} the hipGraph",
+                  file=sys.stderr)
 
     def fwd_bwd():
         if args.eval:
@@ -359,12 +411,16 @@ def main():
         else:
             loss = model.loss(ypred, batch["label"])
         loss.backward()
+        if graph_allreduce:
+            dp.reduce_gradients()
         return loss
 
     # ---- optional hipGraph capture of the whole fwd+loss+bwd launch sequence
     graph = None
     side = torch.cuda.Stream(device)
-    if not args.no_graph:
+    # (gloo's collectives on device tensors synchronise with the host: inside a stream capture that invalidates the
+    # capture and leaves the stream unusable — a sync-BN rehearsal over gloo therefore runs eagerly)
+    if not args.no_graph and not (rehearse and args.sync_bn):
         try:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -389,7 +445,7 @@ def main():
             graph.replay()
         else:
             fwd_bwd()
-        if dp is not None:
+        if dp is not None and not graph_allreduce:      # (otherwise the collective is part of fwd_bwd / the graph)
             dp.reduce_gradients()
 
     for _ in range(args.warmup):
@@ -424,7 +480,9 @@ def main():
             "config": {"workload": w["name"] + (" [REHEARSAL: ranks share one GPU over gloo]" if rehearse else ""),
                        "graphs_per_gpu": w["B"], "global_batch": w["B"] * world,
                        "linkpred": bool(args.linkpred), "hip_graph": graph is not None,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}",
+                       **({"allreduce_in_graph": bool(graph_allreduce and graph is not None),
+                           "batchnorm": "sync" if args.sync_bn else "local"} if world > 1 else {})},
         }
         if world == 1 and not args.eval:
             if w.get("roofline") == "mfma":
