@@ -100,6 +100,11 @@ _PROTOS = {
                             _I, _I, _I, _P, _Z, _P, _Z, _P]),
     "dp_mean_aggregate_fwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "dp_mean_aggregate_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "dp_csr_aggregate": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "dp_sparse_gcn_layer_workspace_bytes": (_Z, [_I, _I, _I]),
+    "dp_sparse_gcn_layer_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "dp_sparse_gcn_layer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _Z,
+                                     _P]),
     "dp_encoder_save_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "dp_encoder_workspace_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "dp_encoder_save_locate": (_I, [C.POINTER(EncoderCfg), _I, _I, C.POINTER(_Z), C.POINTER(_Z)]),

@@ -522,6 +522,80 @@ int dp_mean_aggregate_bwd(const float* dout, int ldo, const int* indptr, const i
     return q.err;
 }
 
+// ------------------------------------------------------------------ N4: CSR GraphConv
+int dp_csr_aggregate(const float* table, int ldt, const int* indptr, const int* indices, float* out, int ldo, int n_rows,
+                     int feat, int mean, float beta, void* stream) {
+    NOTNULL(table); NOTNULL(indptr); NOTNULL(indices); NOTNULL(out);
+    NONNEG(n_rows); NONNEG(feat);
+    Seq q(STREAM(stream), nullptr, 0);
+    csr_aggregate_fwd(q, table, ldt, indptr, indices, out, ldo, n_rows, feat, mean, beta);
+    return q.err;
+}
+namespace {
+void sparse_gcn_fwd_seq(Seq& q, const float* x, int ldx, const int* indptr, const int* indices, const float* W,
+                        const float* bias, float* y, int ldy, float* ax, float* invn, int n, int Fin, int Fout,
+                        int flags) {
+    float* U = q.alloc<float>((size_t)n * Fout);
+    if (q.err) return;
+    csr_aggregate_fwd(q, x, ldx, indptr, indices, ax, Fin, n, Fin, 0, 0.f);
+    if (flags & DP_F_ADD_SELF) axpy(q, ax, x, 1.f, (long)n * Fin);          // (x is contiguous: checked at the ABI)
+    bgemm(q, ax, W, U, nullptr, 1, n, Fout, Fin, Fin, Fout, Fout, 0, 0, 0, false, false, 1.f, 0.f, 0);
+    rownorm_fwd(q, U, Fout, nullptr, gcp(bias, 0), one_group(Fout), gp(y, ldy), invn, nullptr, n,
+                (flags & DP_F_NORMALIZE) ? 1 : 0, 0);
+}
+void sparse_gcn_bwd_seq(Seq& q, const float* ax, const int* indptr, const int* indices, const int* indptr_t,
+                        const int* indices_t, const float* W, const float* y, int ldy, const float* invn,
+                        const float* dy, int lddy, float* dx, int lddx, float* dW, float* db, int n, int Fin, int Fout,
+                        int flags) {
+    float* dU = q.alloc<float>((size_t)n * Fout);
+    float* dax = dx ? q.alloc<float>((size_t)n * Fin) : nullptr;
+    if (q.err) return;
+    rownorm_bwd(q, gcp(dy, lddy), gcp(nullptr, 0), gcp(y, ldy), invn, nullptr, nullptr, one_group(Fout), dU, Fout,
+                nullptr, 1, n, 0, 0, (flags & DP_F_NORMALIZE) ? 1 : 0);
+    if (db) colsum_batched(q, dU, Fout, 0, n, Fout, db, 0, 1);
+    bgemm(q, ax, dU, dW, nullptr, 1, Fin, Fout, n, Fin, Fout, Fout, 0, 0, 0, true, false, 1.f, 0.f, 0);
+    if (!dx) return;
+    bgemm(q, dU, W, dax, nullptr, 1, n, Fin, Fout, Fout, Fout, Fin, 0, 0, 0, false, true, 1.f, 0.f, 0);
+    if (indptr_t && indices_t) {
+        csr_aggregate_fwd(q, dax, Fin, indptr_t, indices_t, dx, lddx, n, Fin, 0, 0.f);      // dx = A^T dax, a gather
+    } else {
+        zero_fill(q, dx, (size_t)n * Fin * sizeof(float));
+        csr_aggregate_bwd_scatter(q, dax, Fin, indptr, indices, dx, lddx, n, Fin, 0);
+    }
+    if (flags & DP_F_ADD_SELF) axpy(q, dx, dax, 1.f, (long)n * Fin);
+}
+}  // namespace
+size_t dp_sparse_gcn_layer_workspace_bytes(int n, int Fin, int Fout) {
+    size_t f = sized([&](Seq& q) { sparse_gcn_fwd_seq(q, 0, Fin, 0, 0, 0, 0, 0, Fout, 0, 0, n, Fin, Fout, 0); });
+    size_t b = sized([&](Seq& q) {
+        sparse_gcn_bwd_seq(q, 0, 0, 0, 0, 0, 0, 0, Fout, 0, 0, Fout, (float*)1, Fin, 0, 0, n, Fin, Fout, 0);
+    });
+    return f > b ? f : b;
+}
+int dp_sparse_gcn_layer_fwd(const float* x, int ldx, const int* indptr, const int* indices, const float* W,
+                            const float* bias, float* y, int ldy, float* ax, float* invnorm, int n, int Fin, int Fout,
+                            int flags, void* workspace, size_t workspace_bytes, void* stream) {
+    NOTNULL(x); NOTNULL(indptr); NOTNULL(indices); NOTNULL(W); NOTNULL(y); NOTNULL(ax); NOTNULL(invnorm);
+    NONNEG(n); NONNEG(Fin); NONNEG(Fout);
+    DP_CHECK_ARG(!(flags & DP_F_ADD_SELF) || ldx == Fin, "add_self needs a contiguous x (ldx == Fin)");
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    sparse_gcn_fwd_seq(q, x, ldx, indptr, indices, W, bias, y, ldy, ax, invnorm, n, Fin, Fout, flags);
+    return q.err;
+}
+int dp_sparse_gcn_layer_bwd(const float* ax, const int* indptr, const int* indices, const int* indptr_t,
+                            const int* indices_t, const float* W, const float* y, int ldy, const float* invnorm,
+                            const float* dy, int lddy, float* dx, int lddx, float* dW, float* db, int n, int Fin,
+                            int Fout, int flags, void* workspace, size_t workspace_bytes, void* stream) {
+    NOTNULL(ax); NOTNULL(indptr); NOTNULL(indices); NOTNULL(W); NOTNULL(y); NOTNULL(invnorm); NOTNULL(dy); NOTNULL(dW);
+    NONNEG(n); NONNEG(Fin); NONNEG(Fout);
+    DP_CHECK_ARG((indptr_t == nullptr) == (indices_t == nullptr), "indptr_t and indices_t come together");
+    DP_CHECK_ARG(!dx || lddx == Fin, "dx must be contiguous (lddx == Fin)");
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    sparse_gcn_bwd_seq(q, ax, indptr, indices, indptr_t, indices_t, W, y, ldy, invnorm, dy, lddy, dx, lddx, dW, db, n,
+                       Fin, Fout, flags);
+    return q.err;
+}
+
 // ------------------------------------------------------------------ model level
 size_t dp_sizeof_encoder_cfg(void) { return sizeof(dp_encoder_cfg); }
 size_t dp_encoder_save_bytes(const dp_encoder_cfg* cfg) {

@@ -373,6 +373,12 @@ void build_batch(Seq& q, const int* src, const int* dst, const int* edge_ptr, co
 void clip_adam_step(Seq& q, float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_norm,
                     float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt, float* total_norm_out);
 
+// (dp_meanagg.hip) CSR neighbour aggregation: out[i] = (mean | sum) of table[indices[indptr[i]:indptr[i+1]]] (+ beta out)
+void csr_aggregate_fwd(Seq& q, const float* table, int ldt, const int* indptr, const int* indices, float* out, int ldo,
+                       int n_rows, int feat, int mean, float beta);
+void csr_aggregate_bwd_scatter(Seq& q, const float* dout, int ldo, const int* indptr, const int* indices, float* dtable,
+                               int ldt, int n_rows, int feat, int mean);
+
 // (dp_linkpred.hip)
 void linkpred_fwd(Seq& q, const float* S, int lds, const float* adj, const int* num_nodes, float* loss_out,
                   int B, int n, int K, const float* norm = nullptr /*device scalar replacing sum n_b^2*/);

@@ -189,6 +189,26 @@ int dp_mean_aggregate_fwd(const float* table, int ldt, const int* indptr, const 
 int dp_mean_aggregate_bwd(const float* dout, int ldo, const int* indptr, const int* indices, float* dtable,
                           int ldt, int n_rows, int feat, void* stream);
 
+/* ------------------------------------------------------------------ N4  GraphConv on a CSR graph
+ * The padded dense path stores a graph as an [N,N] block (load_data.py:79 drops graphs above max_nodes: DD's largest
+ * has 5 748 nodes = 132 MB dense).  For such graphs the same layer runs on CSR:
+ *     y = l2norm((A x [+ x]) W + b),   A x = sum over the neighbours listed in indices[indptr[i]:indptr[i+1]]
+ * — GraphConv.forward (encoders.py:962-974) on ONE graph.  x [n,Fin] (ldx), y [n,Fout] (ldy); ax [n,Fin] receives
+ * A x (+ x) and invnorm [n] the row norms' reciprocals (both saved for backward).  flags: DP_F_ADD_SELF | DP_F_NORMALIZE.
+ * dp_csr_aggregate is the aggregation alone (mean != 0: the MeanAggregator's mean; beta: out = agg + beta * out). */
+int dp_csr_aggregate(const float* table, int ldt, const int* indptr, const int* indices, float* out, int ldo,
+                     int n_rows, int feat, int mean, float beta, void* stream);
+size_t dp_sparse_gcn_layer_workspace_bytes(int n, int Fin, int Fout);
+int dp_sparse_gcn_layer_fwd(const float* x, int ldx, const int* indptr, const int* indices, const float* W,
+                            const float* bias, float* y, int ldy, float* ax, float* invnorm, int n, int Fin, int Fout,
+                            int flags, void* workspace, size_t workspace_bytes, void* stream);
+/* indptr_t / indices_t: CSR of A^T (the same arrays as the forward's for an undirected graph) — dx is then a gather,
+ * deterministic; NULL: dx is accumulated with float atomics from the forward CSR.  dx may be NULL.  dW, db OVERWRITTEN. */
+int dp_sparse_gcn_layer_bwd(const float* ax, const int* indptr, const int* indices, const int* indptr_t,
+                            const int* indices_t, const float* W, const float* y, int ldy, const float* invnorm,
+                            const float* dy, int lddy, float* dx, int lddx, float* dW, float* db, int n, int Fin,
+                            int Fout, int flags, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ================================================================== model-level entry points
  * One call enqueues the whole forward (or backward) of an encoder, so the Python host pays one
  * FFI crossing per pass instead of ~100.  Parameters live in ONE flat fp32 buffer; the cfg gives
