@@ -68,6 +68,7 @@ _PROTOS = {
     "dp_last_error_string": (C.c_char_p, []),
     "dp_sizeof_encoder_cfg": (_Z, []),
     "dp_bgemm_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _F, _I, _P]),
+    "dp_bgemm_split_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _P]),
     "dp_adj_aggregate": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "dp_adj_pack_ld": (_I, [_I]),
     "dp_adj_pack_bytes": (_Z, [_I, _I]),

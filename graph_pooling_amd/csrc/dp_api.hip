@@ -522,6 +522,19 @@ int dp_mean_aggregate_bwd(const float* dout, int ldo, const int* indptr, const i
     return q.err;
 }
 
+int dp_bgemm_split_bf16(const float* A, const float* B, float* C, int batch, int M, int N, int K, int lda, int ldb,
+                        int ldc, long strideA, long strideB, long strideC, int transA, int transB, float beta,
+                        void* stream) {
+    NOTNULL(A); NOTNULL(B); NOTNULL(C);
+    NONNEG(batch); NONNEG(M); NONNEG(N); NONNEG(K);
+    DP_CHECK_ARG(beta == 0.f || beta == 1.f, "beta must be 0 or 1");
+    Seq q(STREAM(stream), nullptr, 0);
+    GemmDesc d{A, B, C, nullptr, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, transA != 0, transB != 0, 1.f, beta,
+               0, 0, 0, nullptr, 0, 0, 0};
+    gemm_split_bf16(q, d, batch);
+    return q.err;
+}
+
 // ------------------------------------------------------------------ N4: CSR GraphConv
 int dp_csr_aggregate(const float* table, int ldt, const int* indptr, const int* indices, float* out, int ldo, int n_rows,
                      int feat, int mean, float beta, void* stream) {

@@ -208,6 +208,11 @@ __device__ __host__ inline long vs_index(int plane, int CTt, int K8, int cb, int
 // ksplit > 1 cuts K into ranges run by different workgroups (contractions over the node index have K = n
 // = 500 but outputs of a few KB: without it they are 40-80 workgroups walking 16 dependent k-steps).
 void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit = 1);
+// (dp_gemm_split.hip) the same contraction with both operands split into three bf16 planes in registers and multiplied
+// on the bf16 matrix cores (six plane products, fp32 accumulation): fp32-grade results at ~2x the fp32-MFMA rate.
+// Large shapes only, no epilogue options (bias / act / split-K / split_out).
+bool gemm_split_usable(const GemmDesc& d, int batch, int ksplit);
+void gemm_split_bf16(Seq& q, const GemmDesc& d, int batch);
 
 // Column groups of a row: the level-j embed and assign GCN stacks share one pass over the
 // adjacency, so row-wise kernels work on up to two column groups of a joint buffer.

@@ -461,9 +461,30 @@ static void launch_tile(Seq& q, GemmGroupArgs& g, int batch) {
                        q.stream, g);
 }
 
-void bgemm_group(Seq& q, const GemmDesc* d, int count, int batch, int ksplit) {
+void bgemm_group(Seq& q, const GemmDesc* d_in, int count, int batch, int ksplit) {
     if (!q.ok() || batch <= 0 || count <= 0) return;
     if (ksplit < 1) ksplit = 1;
+    // big products between two general fp32 operands go to the split-bf16 kernel (dp_gemm_split.hip), one launch each;
+    // what is left shares the grouped fp32-MFMA launch below
+    GemmDesc rest[GEMM_GROUP_MAX];
+    const GemmDesc* d = d_in;
+    if (!q.pred && count <= GEMM_GROUP_MAX) {
+        int nrest = 0;
+        bool any = false;
+        for (int i = 0; i < count; ++i) {
+            if (gemm_split_usable(d_in[i], batch, d_in[i].nosplit ? 1 : ksplit)) {
+                gemm_split_bf16(q, d_in[i], batch);
+                any = true;
+            } else {
+                rest[nrest++] = d_in[i];
+            }
+        }
+        if (any) {
+            if (nrest == 0 || !q.ok()) return;
+            d = rest;
+            count = nrest;
+        }
+    }
     if (batch > 65535 || count > GEMM_GROUP_MAX) {
         set_error("bgemm_group: batch %d / count %d out of range", batch, count);
         q.err = DP_ERR_INVALID_ARG;

@@ -58,6 +58,15 @@ int dp_bgemm_f32(const float* A, const float* B, float* C, const float* bias, in
                  int K, int lda, int ldb, int ldc, long strideA, long strideB, long strideC, int transA,
                  int transB, float alpha, float beta, int act, void* stream);
 
+/* The same contraction (alpha = 1, beta in {0, 1}, no bias / activation) with BOTH fp32 operands split exactly into
+ * three bf16 planes on the way to LDS and multiplied on the bf16 matrix cores — six plane products, fp32 accumulation;
+ * the dropped cross terms are <= 2^-23 of a product, so the result is fp32-grade (not bit-identical to dp_bgemm_f32).
+ * dp_bgemm_f32 and the encoder plans take this kernel by themselves for large shapes (M, N >= 96, K >= 64, >= 256
+ * output tiles of 128 x 128); this entry runs it on any shape. */
+int dp_bgemm_split_bf16(const float* A, const float* B, float* C, int batch, int M, int N, int K, int lda, int ldb,
+                        int ldc, long strideA, long strideB, long strideC, int transA, int transB, float beta,
+                        void* stream);
+
 /* ------------------------------------------------------------------ adjacency aggregation
  * U[b] = op(adj[b]) · V[b] (+ beta U[b]):  adj [B,n,n], V [B,n,C] (ldv), U [B,n,C] (ldu); trans != 0 uses
  * adj^T.  The HBM-bound pass over the padded dense adjacency — torch.matmul(adj, x), encoders.py:965,

@@ -60,6 +60,45 @@ def test_bgemm_shapes(lib, tA, tB, M, N, K):
     close(Cd, ref.float(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K,beta", [(256, 256, 1024, 0.0), (1024, 256, 256, 1.0), (300, 296, 90, 0.0),
+                                        (129, 97, 65, 1.0), (7, 5, 3, 0.0), (128, 128, 32, 0.0)])
+def test_bgemm_split_bf16_is_fp32_grade(lib, tA, tB, M, N, K, beta):
+    """dp_bgemm_split_bf16: both fp32 operands split into three bf16 planes, six plane products on the bf16 MFMA.
+    Wide-dynamic-range operands (values over 6 decades, mixed signs); against an fp64 product the error must be within a
+    few fp32 roundings of the row's |a|.|b| — the bar an fp32 accumulation itself meets (rtol 2e-6 of sum |a_k b_k|)."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    batch = 2
+
+    def wide(*shape):
+        return torch.randn(*shape, generator=g) * torch.pow(10.0, torch.randint(-3, 3, shape, generator=g).float())
+    A = wide(batch, K, M) if tA else wide(batch, M, K)
+    Bm = wide(batch, N, K) if tB else wide(batch, K, N)
+    C0 = torch.randn(batch, M, N, generator=g)
+    Ad, Bd, Cd = dev(A), dev(Bm), dev(C0)
+    lda, ldb = A.shape[2], Bm.shape[2]
+    _lib.check(lib.dp_bgemm_split_bf16(Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), batch, M, N, K, lda, ldb, N,
+                                       A.shape[1] * lda, Bm.shape[1] * ldb, M * N, tA, tB, beta, S()))
+    opA = (A.transpose(1, 2) if tA else A).double()
+    opB = (Bm.transpose(1, 2) if tB else Bm).double()
+    ref = opA @ opB + beta * C0.double()
+    mag = opA.abs() @ opB.abs() + beta * C0.double().abs()
+    err = (Cd.cpu().double() - ref).abs()
+    assert torch.isfinite(Cd).all()
+    assert float((err / mag).max()) < 2e-6, float((err / mag).max())
+
+
+def test_bgemm_split_bf16_identity_asymmetric(lib):
+    # A = I against an asymmetric B: catches a transposed C write or a k permutation that differs between the operands
+    M = N = K = 160
+    Bm = torch.arange(K * N, dtype=torch.float32).reshape(K, N) * 0.25
+    Ad, Bd = dev(torch.eye(M).repeat(2, 1, 1)), dev(Bm)
+    Cd = torch.zeros(2, M, N, device="cuda")
+    _lib.check(lib.dp_bgemm_split_bf16(Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), 2, M, N, K, K, N, N, M * K, 0, M * N,
+                                       0, 0, 0.0, S()))
+    close(Cd, Bm.repeat(2, 1, 1), 0, 0)
+
+
 def test_bgemm_asymmetric_identity_and_strides(lib):
     # A = I with an asymmetric B catches a transposed C-write; leading dims > widths; broadcast B (stride 0)
     M = N = K = 48
