@@ -51,6 +51,9 @@ struct SplitGemmArgs {
     int tA, tB;
     float beta;       // 0 or 1
     int tilesN;
+    // optional second output: the exact 3-plane bf16 split of C in the layout the bf16 aggregation reads (GemmDesc)
+    unsigned short* split_out;
+    int split_ct, split_k8, split_c0;
 };
 
 // 16 fp32 values of one operand slab share: q[i] = four consecutive elements along the operand's contiguous dimension
@@ -59,38 +62,74 @@ struct SgRegs {
 };
 
 // ---- global -> registers.  KC: k is the contiguous dimension (element (r, k) at p[r * ld + k]); else p[k * ld + r].
-// Loads are unconditional on clamped addresses; quads that stick out of the operand are re-read element-wise (tile
-// edges only).
+// Every load is ONE unconditional 16-byte request from a clamped, always-valid address — no branch and no select sits
+// between the eight requests of a slab, so they share one memory round trip (a per-quad `if (inside) load4 else
+// load1 x 4` made hipcc wait for each quad in turn: 9.8k cycles per k-slab against a 3k MFMA budget).
+// EDGE = false: the whole 128 x 32 slab lies inside the operand.  EDGE = true (tiles on the operand's rim, the last
+// partial k-slab): a quad that sticks out of the contiguous dimension is read shifted back so that it ENDS at the
+// rim, and sg_fix() — after the loads are in flight — undoes the shift and zeroes what lies outside.
 template <bool KC>
+__device__ __forceinline__ void sg_coords(int i, int r0, int k0, int& c, int& o) {
+    const int t = threadIdx.x;
+    int r, k;
+    if (KC) {
+        const int slot = t + 256 * i;           // (row, k-quad): 8 quads per row
+        r = r0 + (slot >> 3);
+        k = k0 + (slot & 7) * 4;
+    } else {
+        r = r0 + (t >> 3) * 4;                  // one 4 k x 4 row block per thread: k-block t & 7, row block t >> 3
+        k = k0 + (t & 7) * 4 + i;
+    }
+    c = KC ? k : r;                             // contiguous coordinate of the quad's first element
+    o = KC ? r : k;                             // the other coordinate
+}
+template <bool KC, bool EDGE>
 __device__ __forceinline__ void sg_load(const float* __restrict__ p, int ld, int r0, int k0, int rmax, int kmax,
                                         SgRegs& s) {
-    const int t = threadIdx.x;
+    const int cmax = KC ? kmax : rmax, omax = KC ? rmax : kmax;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int r, k;                                   // first element of quad i
-        if (KC) {
-            const int slot = t + 256 * i;           // (row, k-quad): 8 quads per row
-            r = r0 + (slot >> 3);
-            k = k0 + (slot & 7) * 4;
-        } else {
-            r = r0 + (t >> 3) * 4;                  // one 4 k x 4 row block per thread: k-block t & 7, row block t >> 3
-            k = k0 + (t & 7) * 4 + i;
+        int c, o;
+        sg_coords<KC>(i, r0, k0, c, o);
+        if (EDGE) {
+            c = min(c, cmax - 4);
+            o = min(o, omax - 1);
         }
-        const int c = KC ? k : r, o = KC ? r : k;   // contiguous / other coordinate
-        const int cmax = KC ? kmax : rmax, omax = KC ? rmax : kmax;
-        const float* row = p + (long)min(o, omax - 1) * ld;
-        if (c + 4 <= cmax) {
-            s.q[i] = *reinterpret_cast<const sg_f32x4_u*>(row + c);
-        } else {
+        s.q[i] = *reinterpret_cast<const sg_f32x4_u*>(p + (long)o * ld + c);
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void sg_fix(int r0, int k0, int rmax, int kmax, SgRegs& s) {
+    const int cmax = KC ? kmax : rmax, omax = KC ? rmax : kmax;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s.q[i][j] = c + j < cmax ? row[c + j] : 0.f;
-        }
-        if (o >= omax) s.q[i] = (sg_f32x4){0.f, 0.f, 0.f, 0.f};     // past K (or past the rows: never stored)
+    for (int i = 0; i < 4; ++i) {
+        int c, o;
+        sg_coords<KC>(i, r0, k0, c, o);
+        const int shift = c - min(c, cmax - 4);          // 0 inside; 1..3 on the rim; >= 4 wholly outside
+        const bool dead = o >= omax;
+        const sg_f32x4 v = s.q[i];
+        sg_f32x4 w;
+        w[0] = shift == 0 ? v[0] : shift == 1 ? v[1] : shift == 2 ? v[2] : shift == 3 ? v[3] : 0.f;
+        w[1] = shift == 0 ? v[1] : shift == 1 ? v[2] : shift == 2 ? v[3] : 0.f;
+        w[2] = shift == 0 ? v[2] : shift == 1 ? v[3] : 0.f;
+        w[3] = shift == 0 ? v[3] : 0.f;
+        s.q[i] = dead ? (sg_f32x4){0.f, 0.f, 0.f, 0.f} : w;
     }
 }
 
+// v = h + m + l exactly: round to bf16 (gfx950's v_cvt_pk_bf16_f32, round-to-nearest-even), subtract — the residual
+// of a nearest rounding is exact in fp32 — and repeat.  Three conversions, two shifts back and two subtractions per
+// element (the integer formulation of dp_common.h's bf16_split3 is ~16 vector instructions: at 32 elements per thread
+// and k-slab it, not the MFMA, set the pace of this kernel).
 __device__ __forceinline__ void sg_split(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
-    bf16_split3(v, h, m, l);
+    const __bf16 hb = (__bf16)v;
+    const float r1 = v - (float)hb;
+    const __bf16 mb = (__bf16)r1;
+    const float r2 = r1 - (float)mb;
+    const __bf16 lb = (__bf16)r2;
+    h = __builtin_bit_cast(unsigned short, hb);
+    m = __builtin_bit_cast(unsigned short, mb);
+    l = __builtin_bit_cast(unsigned short, lb);
 }
 
 // ---- registers -> LDS planes [plane][row][k]
@@ -157,20 +196,30 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
         for (int j = 0; j < 4; ++j) acc[i][j] = (sg_f32x4){0.f, 0.f, 0.f, 0.f};
 
     // A is k-contiguous when NOT transposed (A[m][k]); B is k-contiguous when transposed (B[n][k])
-    SgRegs ra, rb;
-    sg_load<!TA>(A, a.lda, m0, 0, a.M, a.K, ra);
-    sg_load<TB>(B, a.ldb, n0, 0, a.N, a.K, rb);
+    // The next slab's loads are in flight in registers while the current one is multiplied.  (Two slabs in flight —
+    // 32 more registers — put the kernel at 312 VGPRs, one workgroup per CU instead of two: 95-105 TFLOP/s against
+    // 124-140.)
+    SgRegs ra0, rb0;
     const int nk = (a.K + SG_KT - 1) / SG_KT;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt > 0) __syncthreads();                       // the previous slab's readers are done
-        sg_store<!TA>(As, ra);
-        sg_store<TB>(Bs, rb);
-        __syncthreads();
-        if (kt + 1 < nk) {
-            sg_load<!TA>(A, a.lda, m0, (kt + 1) * SG_KT, a.M, a.K, ra);
-            sg_load<TB>(B, a.ldb, n0, (kt + 1) * SG_KT, a.N, a.K, rb);
-        }
-        // ---- 64 x 64 x 32 per wave
+    const bool rimA = m0 + SG_BM > a.M, rimB = n0 + SG_BN > a.N;      // wave-uniform
+    auto fetch = [&](int kt, SgRegs& ra, SgRegs& rb) {
+        const int k0 = kt * SG_KT;
+        const bool tail = k0 + SG_KT > a.K;
+        if (rimA || tail) sg_load<!TA, true>(A, a.lda, m0, k0, a.M, a.K, ra);
+        else sg_load<!TA, false>(A, a.lda, m0, k0, a.M, a.K, ra);
+        if (rimB || tail) sg_load<TB, true>(B, a.ldb, n0, k0, a.N, a.K, rb);
+        else sg_load<TB, false>(B, a.ldb, n0, k0, a.N, a.K, rb);
+    };
+    auto fix = [&](int kt, SgRegs& ra, SgRegs& rb) {        // after the wait the LDS write needs anyway
+        const int k0 = kt * SG_KT;
+        const bool tail = k0 + SG_KT > a.K;
+        if (rimA || tail) sg_fix<!TA>(m0, k0, a.M, a.K, ra);
+        if (rimB || tail) sg_fix<TB>(n0, k0, a.N, a.K, rb);
+    };
+    auto multiply = [&]() {
+        // ---- 64 x 64 x 32 per wave.  The six plane products of a column tile run product by product over the four
+        // row tiles: consecutive MFMAs write different accumulators (a chain of six on one accumulator stalls on
+        // each result); smallest terms first.
         sg_s16x8 af[3][4];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -184,16 +233,28 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
             for (int p = 0; p < 3; ++p)
                 bf[p] = *reinterpret_cast<const sg_s16x8*>(Bs + p * SG_PLANE + (wc * 64 + j * 16 + l15) * SG_LDK + kq * 8);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // smallest terms first
-                SG_MFMA(af[1][i], bf[1], acc[i][j]);
-                SG_MFMA(af[0][i], bf[2], acc[i][j]);
-                SG_MFMA(af[2][i], bf[0], acc[i][j]);
-                SG_MFMA(af[0][i], bf[1], acc[i][j]);
-                SG_MFMA(af[1][i], bf[0], acc[i][j]);
-                SG_MFMA(af[0][i], bf[0], acc[i][j]);
-            }
+            for (int i = 0; i < 4; ++i) SG_MFMA(af[1][i], bf[1], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) SG_MFMA(af[0][i], bf[2], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) SG_MFMA(af[2][i], bf[0], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) SG_MFMA(af[0][i], bf[1], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) SG_MFMA(af[1][i], bf[0], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) SG_MFMA(af[0][i], bf[0], acc[i][j]);
         }
+    };
+    fetch(0, ra0, rb0);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt > 0) __syncthreads();                       // the previous slab's readers are done
+        fix(kt, ra0, rb0);
+        sg_store<!TA>(As, ra0);
+        sg_store<TB>(Bs, rb0);
+        __syncthreads();
+        if (kt + 1 < nk) fetch(kt + 1, ra0, rb0);
+        multiply();
     }
     // ---- C tile: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
@@ -202,6 +263,27 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
         for (int j = 0; j < 4; ++j) {
             const int col = n0 + wc * 64 + j * 16 + l15;
             if (col >= a.N) continue;
+            if (a.split_out) {
+                // this lane holds 4 consecutive rows of one column: half of a k8 group -> one 8-byte store per plane
+                // (rows M .. 8 * split_k8 - 1 are the operand's zero padding)
+                const int row0 = m0 + wr * 64 + i * 16 + kq * 4;
+                if (row0 < a.split_k8 * 8) {
+                    const int vc = a.split_c0 + col;
+                    unsigned short* vb = a.split_out + (long)b * 3 * a.split_ct * a.split_k8 * 128;
+                    sg_u16x4 h, m, l;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        unsigned short hh, mm, ll;
+                        sg_split(row0 + r < a.M ? acc[i][j][r] : 0.f, hh, mm, ll);
+                        h[r] = hh; m[r] = mm; l[r] = ll;
+                    }
+                    const long o = vs_index(0, a.split_ct, a.split_k8, vc >> 4, row0 >> 3, vc & 15, row0 & 7);
+                    const long pl = (long)a.split_ct * a.split_k8 * 128;
+                    *reinterpret_cast<sg_u16x4*>(vb + o) = h;
+                    *reinterpret_cast<sg_u16x4*>(vb + o + pl) = m;
+                    *reinterpret_cast<sg_u16x4*>(vb + o + 2 * pl) = l;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wr * 64 + i * 16 + kq * 4 + r;
@@ -230,20 +312,25 @@ __global__ __launch_bounds__(256) void k_gemm_split_bf16(SplitGemmArgs a) {
 // a contraction long enough to amortise the prologue, and enough tiles to fill the chip.
 bool gemm_split_usable(const GemmDesc& d, int batch, int ksplit) {
     if (knobs().no_split_gemm) return false;
-    if (d.bias || d.act || d.atomic || d.split_out || d.fix_part || d.sK != 0 || ksplit > 1) return false;
+    if (d.bias || d.act || d.atomic || d.fix_part || ksplit > 1) return false;      // (sK only matters under split-K)
+    if (d.split_out && d.beta != 0.f) return false;
     if (d.alpha != 1.f || !(d.beta == 0.f || d.beta == 1.f)) return false;
-    if (d.M < 96 || d.N < 96 || d.K < 64) return false;
+    if (d.M < 96 || d.N < 96 || d.K < 64) return false;       // (the rim loads also need every extent >= 4)
     const long tiles = (long)((d.M + SG_BM - 1) / SG_BM) * ((d.N + SG_BN - 1) / SG_BN) * batch;
     return tiles >= 256;
 }
 
 void gemm_split_bf16(Seq& q, const GemmDesc& d, int batch) {
     if (!q.ok() || batch <= 0 || d.M <= 0 || d.N <= 0) return;
+    if (d.M < 4 || d.N < 4 || d.K < 4) {          // no 16-byte quad fits an extent: the fp32-MFMA kernel takes it
+        bgemm_group(q, &d, 1, batch, 1);
+        return;
+    }
     static DynLdsOnce attr;
     ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_gemm_split_bf16), SG_LDS_BYTES, "k_gemm_split_bf16");
     if (!q.ok()) return;
     SplitGemmArgs a{d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.sA, d.sB, d.sC, d.tA ? 1 : 0, d.tB ? 1 : 0, d.beta,
-                    (d.N + SG_BN - 1) / SG_BN};
+                    (d.N + SG_BN - 1) / SG_BN, d.split_out, d.split_ct, d.split_k8, d.split_c0};
     const int tiles = ((d.M + SG_BM - 1) / SG_BM) * a.tilesN;
     hipLaunchKernelGGL(k_gemm_split_bf16, dim3(tiles, batch), dim3(256), SG_LDS_BYTES, q.stream, a);
     q.check_launch("gemm_split_bf16");

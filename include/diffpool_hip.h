@@ -62,7 +62,7 @@ int dp_bgemm_f32(const float* A, const float* B, float* C, const float* bias, in
  * three bf16 planes on the way to LDS and multiplied on the bf16 matrix cores — six plane products, fp32 accumulation;
  * the dropped cross terms are <= 2^-23 of a product, so the result is fp32-grade (not bit-identical to dp_bgemm_f32).
  * dp_bgemm_f32 and the encoder plans take this kernel by themselves for large shapes (M, N >= 96, K >= 64, >= 256
- * output tiles of 128 x 128); this entry runs it on any shape. */
+ * output tiles of 128 x 128); this entry runs it on any shape with every extent >= 4 (smaller ones: dp_bgemm_f32). */
 int dp_bgemm_split_bf16(const float* A, const float* B, float* C, int batch, int M, int N, int K, int lda, int ldb,
                         int ldc, long strideA, long strideB, long strideC, int transA, int transB, float beta,
                         void* stream);
