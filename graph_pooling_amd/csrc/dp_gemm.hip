@@ -302,7 +302,18 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, int ks, float* lds
                 }
             }
         // the partial is at the device's coherence point once its stores have been acknowledged; a full fence
-        // (`__threadfence()`: L2 write-back + invalidate per workgroup) made this launch 70 us slower
+        // (`__threadfence()`: L2 write-back + invalidate per workgroup) made this launch 70 us slower.
+        // MEMORY-MODEL NOTE: there is no release/acquire pair in this source.  The ordering rests on gfx950 ISA
+        // behaviour, not on the HIP memory model: (1) agent-scope relaxed atomic stores are write-through (sc1) and
+        // `s_waitcnt vmcnt(0)` returns only when every one of them has been acknowledged at the device's coherence
+        // point; (2) the workgroup barrier orders all waves' stores before thread 0's ticket; (3) the ticket is an
+        // agent-scope atomic RMW performed at that same coherence point, so whoever draws the last ticket does so
+        // after every partial is visible there; (4) the reader's agent-scope relaxed atomic loads are served past
+        // the XCD-local L2.  The portable form (ticket fetch_add with __ATOMIC_ACQ_REL at agent scope) adds a
+        // buffer_wbl2 / buffer_inv pair per workgroup — the 70 us above.  The guard for this assumption is
+        // tests/test_gpu_model.py::test_forward_is_bit_reproducible_with_split_k_pooling (40 runs, bit-identical)
+        // and tools/race_hunt.py (2 500 runs).  The whole-level kernels' grid barrier (dp_small.hip) uses the same
+        // store / wait / ticket / load pattern.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // (also: every wave is done reading the operand slabs)
         int* ticket = reinterpret_cast<int*>(lds);

@@ -481,9 +481,12 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
 // Memory model (this is the part that is easy to get wrong on a multi-XCD part: each XCD has its own L2, and plain
 // stores / loads of different XCDs are not coherent inside one kernel): the exchanged partials are written with
 // agent-scope atomic stores (write-through to the device's coherence point) and read with agent-scope atomic loads
-// (served past the XCD-local L2).  The ticket is an agent-scope RELEASE fetch-add issued after a workgroup barrier,
-// the spin an agent-scope ACQUIRE load: a proper release/acquire pair, so the ordering does not rest on ISA
-// behaviour.  Its cost was measured at the DD shape: ~1.5 us per barrier.
+// (served past the XCD-local L2); every thread waits for the acknowledgement of its stores (s_waitcnt vmcnt(0))
+// before the workgroup barrier that precedes the ticket.  The ticket and the spin are RELAXED agent-scope atomics
+// by default — the same ISA-level argument as the split-K combine (dp_gemm.hip, MEMORY-MODEL NOTE); building with
+// -DDP_BAR_ACQREL makes them a RELEASE fetch-add / ACQUIRE load pair (measured at the DD shape: no difference in
+// kernel time, 22.6 vs 23.0 us — the barrier's ~1.7 us is arrival skew plus one atomic round trip, and the
+// exchanged data never sit in a cache the fences would have to write back).
 // The tickets are zeroed in stream order by an earlier launch of the same sequence (never by a memset node).
 constexpr int SM_SPIN_LIMIT = 1 << 22;
 constexpr int SM_BMAX16 = 8;      // whole-level kernels take B <= 128 graphs (16 lanes x 8 partial pairs per node)
