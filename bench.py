@@ -316,7 +316,7 @@ def _collective_capture_works(dist, device, world, rank):
         g = torch.cuda.CUDAGraph()
         t.fill_(float(rank + 1))
         torch.cuda.synchronize()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             dist.all_reduce(t, group=grp)
         t.fill_(float(rank + 1))
         g.replay()
@@ -371,6 +371,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # whole-step graph capture next to a collective library: no asynchronous error-handling thread poking at
+        # events while a stream is capturing (PyTorch's CUDA-graphs-with-NCCL note)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        os.environ.setdefault("NCCL_ASYNC_ERROR_HANDLING", "0")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -430,7 +434,9 @@ def main():
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             model.zero_grad(set_to_none=True)
-            with torch.cuda.graph(g):
+            # N > 1: other threads of this process (the collective library's watchdog) may touch the runtime while
+            # this thread captures; only calls of THIS thread can invalidate the capture
+            with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
                 static_loss = fwd_bwd()
             graph = g
         except Exception as e:                      # noqa: BLE001
