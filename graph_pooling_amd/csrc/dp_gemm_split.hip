@@ -54,6 +54,8 @@ struct SplitGemmArgs {
     // optional second output: the exact 3-plane bf16 split of C in the layout the bf16 aggregation reads (GemmDesc)
     unsigned short* split_out;
     int split_ct, split_k8, split_c0;
+    const float* bias;   // [N] added to every row, or null
+    int act;             // 1: ReLU
 };
 
 // 16 fp32 values of one operand slab share: q[i] = four consecutive elements along the operand's contiguous dimension
@@ -263,6 +265,15 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
         for (int j = 0; j < 4; ++j) {
             const int col = n0 + wc * 64 + j * 16 + l15;
             if (col >= a.N) continue;
+            if (a.bias) {
+                const float bv = a.bias[col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += bv;
+            }
+            if (a.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+            }
             if (a.split_out) {
                 // this lane holds 4 consecutive rows of one column: half of a k8 group -> one 8-byte store per plane
                 // (rows M .. 8 * split_k8 - 1 are the operand's zero padding)
@@ -312,7 +323,8 @@ __global__ __launch_bounds__(256) void k_gemm_split_bf16(SplitGemmArgs a) {
 // a contraction long enough to amortise the prologue, and enough tiles to fill the chip.
 bool gemm_split_usable(const GemmDesc& d, int batch, int ksplit) {
     if (knobs().no_split_gemm) return false;
-    if (d.bias || d.act || d.atomic || d.fix_part || ksplit > 1) return false;      // (sK only matters under split-K)
+    if (d.atomic || d.fix_part || ksplit > 1) return false;      // (sK only matters under split-K)
+    if ((d.bias || d.act) && d.beta != 0.f) return false;
     if (d.split_out && d.beta != 0.f) return false;
     if (d.alpha != 1.f || !(d.beta == 0.f || d.beta == 1.f)) return false;
     if (d.M < 96 || d.N < 96 || d.K < 64) return false;       // (the rim loads also need every extent >= 4)
@@ -330,7 +342,7 @@ void gemm_split_bf16(Seq& q, const GemmDesc& d, int batch) {
     ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_gemm_split_bf16), SG_LDS_BYTES, "k_gemm_split_bf16");
     if (!q.ok()) return;
     SplitGemmArgs a{d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.sA, d.sB, d.sC, d.tA ? 1 : 0, d.tB ? 1 : 0, d.beta,
-                    (d.N + SG_BN - 1) / SG_BN, d.split_out, d.split_ct, d.split_k8, d.split_c0};
+                    (d.N + SG_BN - 1) / SG_BN, d.split_out, d.split_ct, d.split_k8, d.split_c0, d.bias, d.act};
     const int tiles = ((d.M + SG_BM - 1) / SG_BM) * a.tilesN;
     hipLaunchKernelGGL(k_gemm_split_bf16, dim3(tiles, batch), dim3(256), SG_LDS_BYTES, q.stream, a);
     q.check_launch("gemm_split_bf16");

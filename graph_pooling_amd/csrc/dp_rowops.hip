@@ -464,6 +464,7 @@ struct RownormBwdArgs {
     int rows_per_chunk;
     int has_relu, has_bn, normalize;
     int Bs;               // graphs in part2 (B, or B x ranks under sync-BN)
+    int means_ready;      // big batches: k_bn_bwd_finalize left (m0, m1) of every (node, group) in part2's first block
 };
 // grid (chunks, B): a workgroup owns a contiguous chunk of rows of ONE graph, so the column sums of dU
 // (the bias gradients, db = sum_rows dU) can be accumulated in LDS and leave as one partial per workgroup.
@@ -511,17 +512,21 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
             {
                 const long pstride = (long)a.n * a.g.G * 2;
                 const float* p = (a.has_bn ? a.part2 : dx) + (a.has_bn ? ((long)node * a.g.G + g) * 2 : 0);
-                const int nb = a.has_bn ? a.Bs : 0;
+                const int nb = (a.has_bn && !a.means_ready) ? a.Bs : 0;
                 for (int bb = tl; bb < nb; bb += 16) {
                     s0 += p[bb * pstride];
                     s1 += p[bb * pstride + 1];
+                }
+                if (a.means_ready) {          // (m0, m1) already combined: every lane reads the same pair
+                    s0 = p[0];
+                    s1 = p[1];
                 }
             }
             // ---- arithmetic
             const float cnt = (float)a.Bs * (float)w;
             const float rstd = a.has_bn ? rstd_l : 1.f;
-            const float m0 = a.has_bn ? team_sum(s0) / cnt : 0.f;
-            const float m1 = a.has_bn ? team_sum(s1) / cnt : 0.f;
+            const float m0 = !a.has_bn ? 0.f : a.means_ready ? s0 : team_sum(s0) / cnt;
+            const float m1 = !a.has_bn ? 0.f : a.means_ready ? s1 : team_sum(s1) / cnt;
             const float inv = a.normalize ? inv_l : 1.f;
             const bool project = a.normalize && (inv < 1.0f / L2_EPS);
             float dot = 0.f;
@@ -554,14 +559,19 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
             rstd = a.stats[((long)node * a.g.G + g) * 2 + 1];
             const long pstride = (long)a.n * a.g.G * 2;
             const float* p = a.part2 + ((long)node * a.g.G + g) * 2;
-            float s0 = 0.f, s1 = 0.f;
-            for (int bb = tl; bb < a.Bs; bb += 16) {
-                s0 += p[bb * pstride];
-                s1 += p[bb * pstride + 1];
+            if (a.means_ready) {
+                m0 = p[0];
+                m1 = p[1];
+            } else {
+                float s0 = 0.f, s1 = 0.f;
+                for (int bb = tl; bb < a.Bs; bb += 16) {
+                    s0 += p[bb * pstride];
+                    s1 += p[bb * pstride + 1];
+                }
+                const float cnt = (float)a.Bs * (float)w;
+                m0 = team_sum(s0) / cnt;
+                m1 = team_sum(s1) / cnt;
             }
-            const float cnt = (float)a.Bs * (float)w;
-            m0 = team_sum(s0) / cnt;
-            m1 = team_sum(s1) / cnt;
         }
         const float inv = a.normalize ? a.invn[row * a.g.G + g] : 1.f;
         const bool project = a.normalize && (inv < 1.0f / L2_EPS);
@@ -621,6 +631,30 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
         }
     }
 }
+// Big batches: the B x ranks partial pairs of a (node, group) are combined ONCE, in place (the result overwrites the
+// pair of graph 0), instead of in every one of the B rows of that node — at B = 256 the on-the-fly combine was 256
+// scattered 8-byte loads per row item: 325 us per launch against ~70 (the forward pass has k_bn_finalize for the same
+// reason).
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(float* part2, int Bs, int n, RowGroups g) {
+    const int tl = threadIdx.x & 15;
+    const long it = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (it >= (long)n * g.G) return;
+    const int gi = (int)(it % g.G);
+    const long pstride = (long)n * g.G * 2;
+    float* p = part2 + it * 2;
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = tl; b < Bs; b += 16) {
+        s0 += p[b * pstride];
+        s1 += p[b * pstride + 1];
+    }
+    s0 = team_sum(s0);
+    s1 = team_sum(s1);
+    const float cnt = (float)Bs * (float)g.w[gi];
+    if (tl == 0) {
+        p[0] = s0 / cnt;
+        p[1] = s1 / cnt;
+    }
+}
 int rownorm_bwd_chunks(int n) { return (n + 7) / 8; }
 void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const float* invn, const float* stats,
                  const float* part2, RowGroups g, float* dU, int ldu, const GroupPtrs* dbias, int B, int n,
@@ -635,7 +669,14 @@ void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const flo
     }
     const int ct = g.c0[g.G - 1] + g.w[g.G - 1];
     RownormBwdArgs a{dx, xhat, y, invn, stats, part2, g, dU, ldu, db, want, vs, (ct + 15) / 16, ((n + 31) / 32) * 4,
-                     B, n, 8, has_relu, has_bn, normalize, Bs};
+                     B, n, 8, has_relu, has_bn, normalize, Bs, 0};
+    if (has_bn && Bs > 32) {
+        // (part2 is plan scratch; the combined means go where graph 0's pair was)
+        hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)(((long)n * g.G + 15) / 16)), dim3(256), 0, q.stream,
+                           const_cast<float*>(part2), Bs, n, g);
+        q.check_launch("bn_bwd_finalize");
+        a.means_ready = 1;
+    }
     const int maxw = g.G == 2 && g.w[1] > g.w[0] ? g.w[1] : g.w[0];
     const dim3 grid(rownorm_bwd_chunks(n), B);
     const size_t lds = ((want ? 16 : 0) + (vs ? 8 : 0)) * ct * sizeof(float);

@@ -20,9 +20,9 @@ def run(name, M, N, K, tA, tB, batch=256):
         lib.dp_bgemm_split_bf16(A.data_ptr(), B.data_ptr(), C.data_ptr(), batch, M, N, K, lda, ldb, N, sA, sB, M * N, tA, tB,
                                 0.0, st)
 
-    def fp32():        # a bias pointer keeps the call on the fp32-MFMA kernel
+    def fp32():        # alpha != 1 keeps the call on the fp32-MFMA kernel (the split kernel takes alpha = 1 only)
         lib.dp_bgemm_f32(A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr(), batch, M, N, K, lda, ldb, N, sA, sB,
-                         M * N, tA, tB, 1.0, 0.0, 0, st)
+                         M * N, tA, tB, 0.5, 0.0, 0, st)
     out = []
     for fn in (split, fp32):
         for _ in range(3):
