@@ -198,9 +198,14 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
         for (int j = 0; j < 4; ++j) acc[i][j] = (sg_f32x4){0.f, 0.f, 0.f, 0.f};
 
     // A is k-contiguous when NOT transposed (A[m][k]); B is k-contiguous when transposed (B[n][k])
-    // The next slab's loads are in flight in registers while the current one is multiplied.  (Two slabs in flight —
-    // 32 more registers — put the kernel at 312 VGPRs, one workgroup per CU instead of two: 95-105 TFLOP/s against
-    // 124-140.)
+    // The next slab's loads are in flight in registers while the current one is multiplied.  Measured and dropped:
+    // two slabs in flight (312 VGPRs -> one workgroup per CU: 95-105 TFLOP/s against 124-140; forced into 256 VGPRs
+    // with LDS-only barriers instead of __syncthreads' vmcnt(0): no change) — memory latency is not what this kernel
+    // waits for.  Phase ablations at A' = Tt^T S (276 us): without the MFMAs 205 us, without split + LDS stores 146 us,
+    // without the global loads 217 us: the phases of a workgroup hardly overlap, and the split + store phase (~250
+    // vector instructions per thread and slab in dependent convert / shift / subtract chains, two waves per SIMD to
+    // hide them) costs as much as everything else together.  Eight waves per workgroup (half the elements per thread,
+    // four waves per SIMD) is the next form to try.
     SgRegs ra0, rb0;
     const int nk = (a.K + SG_KT - 1) / SG_KT;
     const bool rimA = m0 + SG_BM > a.M, rimB = n0 + SG_BN > a.N;      // wave-uniform

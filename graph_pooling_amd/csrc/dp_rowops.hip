@@ -38,6 +38,10 @@ struct RownormFwdArgs {
     int normalize, stats_mode;
 };
 
+// NK > 0: group widths <= 16 NK — the row (+ add_self operand, + bias) is read ONCE into registers; the three passes
+// of the generic form (norm, write, statistics) re-read it from memory: 342 us against ~150 for the 276-wide assign
+// layer at the ER shape.
+template <int NK>
 __global__ __launch_bounds__(256) void k_rownorm_fwd(RownormFwdArgs a) {
     const int tl = threadIdx.x & 15;
     const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -50,6 +54,49 @@ __global__ __launch_bounds__(256) void k_rownorm_fwd(RownormFwdArgs a) {
         const float* u = a.U + row * a.ldu + c0;
         const float* p = a.P ? a.P + row * a.ldu + c0 : nullptr;
         const float* bias = a.bias.p[g];
+        float* y = a.yout.p[g] + row * a.yout.ld[g];
+        if (NK > 0) {
+            constexpr int NKK = NK > 0 ? NK : 1;
+            float v[NKK];
+#pragma unroll
+            for (int k = 0; k < NKK; ++k) {
+                const int c = min(tl + 16 * k, w - 1);
+                float t = u[c];
+                if (p) t += p[c];
+                if (bias) t += bias[c];
+                v[k] = tl + 16 * k < w ? t : 0.f;
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < NKK; ++k) ss += v[k] * v[k];
+            ss = team_sum(ss);
+            const float inv = a.normalize ? 1.f / fmaxf(sqrtf(ss), L2_EPS) : 1.f;
+            float s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NKK; ++k) {
+                v[k] *= inv;
+                if (tl + 16 * k < w) y[tl + 16 * k] = v[k];
+                s1 += a.stats_mode == 1 ? fmaxf(v[k], 0.f) : v[k];
+            }
+            if (tl == 0 && a.invn) a.invn[it] = inv;
+            if (a.stats_mode && a.part) {
+                s1 = team_sum(s1);
+                const float mean = s1 / (float)w;
+                float m2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < NKK; ++k) {
+                    float t = a.stats_mode == 1 ? fmaxf(v[k], 0.f) : v[k];
+                    t -= mean;
+                    m2 += tl + 16 * k < w ? t * t : 0.f;
+                }
+                m2 = team_sum(m2);
+                if (tl == 0) {
+                    a.part[it * 2 + 0] = mean;
+                    a.part[it * 2 + 1] = m2;
+                }
+            }
+            continue;
+        }
         float ss = 0.f;
         for (int c = tl; c < w; c += 16) {
             float v = u[c];
@@ -60,7 +107,6 @@ __global__ __launch_bounds__(256) void k_rownorm_fwd(RownormFwdArgs a) {
         ss = team_sum(ss);
         float inv = 1.f;
         if (a.normalize) inv = 1.f / fmaxf(sqrtf(ss), L2_EPS);
-        float* y = a.yout.p[g] + row * a.yout.ld[g];
         float s1 = 0.f;
         for (int c = tl; c < w; c += 16) {
             float v = u[c];
@@ -97,7 +143,13 @@ void rownorm_fwd(Seq& q, const float* U, int ldu, const float* P, GroupCPtrs bia
                  float* invn, float* part, long rows, int normalize, int stats_mode) {
     if (!q.ok() || rows <= 0) return;
     RownormFwdArgs a{U, ldu, P, bias, g, yout, invn, part, rows, normalize, stats_mode};
-    hipLaunchKernelGGL(k_rownorm_fwd, dim3(team_grid(rows * g.G)), dim3(256), 0, q.stream, a);
+    const int maxw = g.G == 2 && g.w[1] > g.w[0] ? g.w[1] : g.w[0];
+    const dim3 grid(team_grid(rows * g.G));
+    if (maxw <= 32) hipLaunchKernelGGL(k_rownorm_fwd<2>, grid, dim3(256), 0, q.stream, a);
+    else if (maxw <= 64) hipLaunchKernelGGL(k_rownorm_fwd<4>, grid, dim3(256), 0, q.stream, a);
+    else if (maxw <= 128) hipLaunchKernelGGL(k_rownorm_fwd<8>, grid, dim3(256), 0, q.stream, a);
+    else if (maxw <= 320) hipLaunchKernelGGL(k_rownorm_fwd<20>, grid, dim3(256), 0, q.stream, a);
+    else hipLaunchKernelGGL(k_rownorm_fwd<0>, grid, dim3(256), 0, q.stream, a);
     q.check_launch("rownorm_fwd");
 }
 
