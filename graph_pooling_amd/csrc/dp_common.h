@@ -135,6 +135,7 @@ struct Knobs {
     bool no_head_fusion;   // DP_NO_HEAD_FUSION: pred_model on the generic GEMM
     bool no_level_fusion;  // DP_NO_LEVEL_FUSION: pooled-level GCN stacks one launch per layer
     bool no_split_gemm;    // DP_NO_SPLIT_GEMM: fp32 MFMA for every GEMM (no split-bf16 products)
+    bool split_gemm_w4;    // DP_SPLIT_GEMM_W4: the 4-wave form of the split GEMM instead of the 8-wave one
 };
 const Knobs& knobs();
 

@@ -59,8 +59,9 @@ struct SplitGemmArgs {
 };
 
 // 16 fp32 values of one operand slab share: q[i] = four consecutive elements along the operand's contiguous dimension
+template <int NQ>
 struct SgRegs {
-    sg_f32x4 q[4];
+    sg_f32x4 q[NQ];
 };
 
 // ---- global -> registers.  KC: k is the contiguous dimension (element (r, k) at p[r * ld + k]); else p[k * ld + r].
@@ -70,29 +71,34 @@ struct SgRegs {
 // EDGE = false: the whole 128 x 32 slab lies inside the operand.  EDGE = true (tiles on the operand's rim, the last
 // partial k-slab): a quad that sticks out of the contiguous dimension is read shifted back so that it ENDS at the
 // rim, and sg_fix() — after the loads are in flight — undoes the shift and zeroes what lies outside.
-template <bool KC>
+// NQ = quads per thread and operand slab: 4 with 256 threads, 2 with 512.
+template <bool KC, int NQ>
 __device__ __forceinline__ void sg_coords(int i, int r0, int k0, int& c, int& o) {
     const int t = threadIdx.x;
+    constexpr int NT = 1024 / NQ;
     int r, k;
     if (KC) {
-        const int slot = t + 256 * i;           // (row, k-quad): 8 quads per row
+        const int slot = t + NT * i;            // (row, k-quad): 8 quads per row
         r = r0 + (slot >> 3);
         k = k0 + (slot & 7) * 4;
-    } else {
+    } else if (NQ == 4) {
         r = r0 + (t >> 3) * 4;                  // one 4 k x 4 row block per thread: k-block t & 7, row block t >> 3
         k = k0 + (t & 7) * 4 + i;
+    } else {
+        r = r0 + (t >> 4) * 4;                  // one 2 k x 4 row block per thread: k-pair t & 15, row block t >> 4
+        k = k0 + (t & 15) * 2 + i;
     }
     c = KC ? k : r;                             // contiguous coordinate of the quad's first element
     o = KC ? r : k;                             // the other coordinate
 }
-template <bool KC, bool EDGE>
+template <bool KC, bool EDGE, int NQ>
 __device__ __forceinline__ void sg_load(const float* __restrict__ p, int ld, int r0, int k0, int rmax, int kmax,
-                                        SgRegs& s) {
+                                        SgRegs<NQ>& s) {
     const int cmax = KC ? kmax : rmax, omax = KC ? rmax : kmax;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NQ; ++i) {
         int c, o;
-        sg_coords<KC>(i, r0, k0, c, o);
+        sg_coords<KC, NQ>(i, r0, k0, c, o);
         if (EDGE) {
             c = min(c, cmax - 4);
             o = min(o, omax - 1);
@@ -100,13 +106,13 @@ __device__ __forceinline__ void sg_load(const float* __restrict__ p, int ld, int
         s.q[i] = *reinterpret_cast<const sg_f32x4_u*>(p + (long)o * ld + c);
     }
 }
-template <bool KC>
-__device__ __forceinline__ void sg_fix(int r0, int k0, int rmax, int kmax, SgRegs& s) {
+template <bool KC, int NQ>
+__device__ __forceinline__ void sg_fix(int r0, int k0, int rmax, int kmax, SgRegs<NQ>& s) {
     const int cmax = KC ? kmax : rmax, omax = KC ? rmax : kmax;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NQ; ++i) {
         int c, o;
-        sg_coords<KC>(i, r0, k0, c, o);
+        sg_coords<KC, NQ>(i, r0, k0, c, o);
         const int shift = c - min(c, cmax - 4);          // 0 inside; 1..3 on the rim; >= 4 wholly outside
         const bool dead = o >= omax;
         const sg_f32x4 v = s.q[i];
@@ -135,13 +141,14 @@ __device__ __forceinline__ void sg_split(float v, unsigned short& h, unsigned sh
 }
 
 // ---- registers -> LDS planes [plane][row][k]
-template <bool KC>
-__device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const SgRegs& s) {
+template <bool KC, int NQ>
+__device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const SgRegs<NQ>& s) {
     const int t = threadIdx.x;
+    constexpr int NT = 1024 / NQ;
     if (KC) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int slot = t + 256 * i;
+        for (int i = 0; i < NQ; ++i) {
+            const int slot = t + NT * i;
             const int r = slot >> 3, k = (slot & 7) * 4;
             sg_u16x4 h, m, l;
 #pragma unroll
@@ -155,7 +162,7 @@ __device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const
             *reinterpret_cast<sg_u16x4*>(d + SG_PLANE) = m;
             *reinterpret_cast<sg_u16x4*>(d + 2 * SG_PLANE) = l;
         }
-    } else {
+    } else if (NQ == 4) {
         // q[i][j] = element (row rb*4 + j, k kb*4 + i): write row j's four k values as one quad
         const int r = (t >> 3) * 4, k = (t & 7) * 4;
 #pragma unroll
@@ -172,14 +179,31 @@ __device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const
             *reinterpret_cast<sg_u16x4*>(d + SG_PLANE) = m;
             *reinterpret_cast<sg_u16x4*>(d + 2 * SG_PLANE) = l;
         }
+    } else {
+        // q[i][j] = element (row rb*4 + j, k kb*2 + i): row j's two k values as one 4-byte store
+        const int r = (t >> 4) * 4, k = (t & 15) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned short h0, m0, l0, h1, m1, l1;
+            sg_split(s.q[0][j], h0, m0, l0);
+            sg_split(s.q[NQ - 1][j], h1, m1, l1);
+            unsigned short* d = img + (r + j) * SG_LDK + k;
+            *reinterpret_cast<unsigned*>(d) = (unsigned)h0 | ((unsigned)h1 << 16);
+            *reinterpret_cast<unsigned*>(d + SG_PLANE) = (unsigned)m0 | ((unsigned)m1 << 16);
+            *reinterpret_cast<unsigned*>(d + 2 * SG_PLANE) = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
     }
 }
 
 #define SG_MFMA(a, b, c) \
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, a), __builtin_bit_cast(sg_bf16x8, b), c, 0, 0, 0)
 
-template <bool TA, bool TB>
+// NW waves per workgroup: 4 (2 x 2, 64 x 64 per wave) or 8 (4 x 2, 32 x 64 per wave: half the split work per thread and
+// four waves per SIMD to hide its dependent convert / subtract chains).
+template <bool TA, bool TB, int NW>
 __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsigned short* lds) {
+    constexpr int MI = 16 / NW;                 // 16-row MFMA tiles per wave: 4 or 2
+    constexpr int NQ = 1024 / (NW * 64);        // quads per thread and operand slab
     const int b = blockIdx.y;
     const int m0 = (tile / a.tilesN) * SG_BM, n0 = (tile % a.tilesN) * SG_BN;
     const float* A = a.A + (long)b * a.sA;
@@ -188,12 +212,12 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
     unsigned short* As = lds;
     unsigned short* Bs = lds + 3 * SG_PLANE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 1, wc = wave & 1;     // NW / 2 wave rows of 16 * MI rows, 2 wave columns of 64
     const int l15 = lane & 15, kq = lane >> 4;
 
-    sg_f32x4 acc[4][4];
+    sg_f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (sg_f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -206,33 +230,33 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
     // vector instructions per thread and slab in dependent convert / shift / subtract chains, two waves per SIMD to
     // hide them) costs as much as everything else together.  Eight waves per workgroup (half the elements per thread,
     // four waves per SIMD) is the next form to try.
-    SgRegs ra0, rb0;
+    SgRegs<NQ> ra0, rb0;
     const int nk = (a.K + SG_KT - 1) / SG_KT;
     const bool rimA = m0 + SG_BM > a.M, rimB = n0 + SG_BN > a.N;      // wave-uniform
-    auto fetch = [&](int kt, SgRegs& ra, SgRegs& rb) {
+    auto fetch = [&](int kt, SgRegs<NQ>& ra, SgRegs<NQ>& rb) {
         const int k0 = kt * SG_KT;
         const bool tail = k0 + SG_KT > a.K;
-        if (rimA || tail) sg_load<!TA, true>(A, a.lda, m0, k0, a.M, a.K, ra);
-        else sg_load<!TA, false>(A, a.lda, m0, k0, a.M, a.K, ra);
-        if (rimB || tail) sg_load<TB, true>(B, a.ldb, n0, k0, a.N, a.K, rb);
-        else sg_load<TB, false>(B, a.ldb, n0, k0, a.N, a.K, rb);
+        if (rimA || tail) sg_load<!TA, true, NQ>(A, a.lda, m0, k0, a.M, a.K, ra);
+        else sg_load<!TA, false, NQ>(A, a.lda, m0, k0, a.M, a.K, ra);
+        if (rimB || tail) sg_load<TB, true, NQ>(B, a.ldb, n0, k0, a.N, a.K, rb);
+        else sg_load<TB, false, NQ>(B, a.ldb, n0, k0, a.N, a.K, rb);
     };
-    auto fix = [&](int kt, SgRegs& ra, SgRegs& rb) {        // after the wait the LDS write needs anyway
+    auto fix = [&](int kt, SgRegs<NQ>& ra, SgRegs<NQ>& rb) {        // after the wait the LDS write needs anyway
         const int k0 = kt * SG_KT;
         const bool tail = k0 + SG_KT > a.K;
-        if (rimA || tail) sg_fix<!TA>(m0, k0, a.M, a.K, ra);
-        if (rimB || tail) sg_fix<TB>(n0, k0, a.N, a.K, rb);
+        if (rimA || tail) sg_fix<!TA, NQ>(m0, k0, a.M, a.K, ra);
+        if (rimB || tail) sg_fix<TB, NQ>(n0, k0, a.N, a.K, rb);
     };
     auto multiply = [&]() {
         // ---- 64 x 64 x 32 per wave.  The six plane products of a column tile run product by product over the four
         // row tiles: consecutive MFMAs write different accumulators (a chain of six on one accumulator stalls on
         // each result); smallest terms first.
-        sg_s16x8 af[3][4];
+        sg_s16x8 af[3][MI];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                af[p][i] = *reinterpret_cast<const sg_s16x8*>(As + p * SG_PLANE + (wr * 64 + i * 16 + l15) * SG_LDK + kq * 8);
+            for (int i = 0; i < MI; ++i)
+                af[p][i] = *reinterpret_cast<const sg_s16x8*>(As + p * SG_PLANE + (wr * 16 * MI + i * 16 + l15) * SG_LDK + kq * 8);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             sg_s16x8 bf[3];
@@ -240,32 +264,32 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
             for (int p = 0; p < 3; ++p)
                 bf[p] = *reinterpret_cast<const sg_s16x8*>(Bs + p * SG_PLANE + (wc * 64 + j * 16 + l15) * SG_LDK + kq * 8);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) SG_MFMA(af[1][i], bf[1], acc[i][j]);
+            for (int i = 0; i < MI; ++i) SG_MFMA(af[1][i], bf[1], acc[i][j]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) SG_MFMA(af[0][i], bf[2], acc[i][j]);
+            for (int i = 0; i < MI; ++i) SG_MFMA(af[0][i], bf[2], acc[i][j]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) SG_MFMA(af[2][i], bf[0], acc[i][j]);
+            for (int i = 0; i < MI; ++i) SG_MFMA(af[2][i], bf[0], acc[i][j]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) SG_MFMA(af[0][i], bf[1], acc[i][j]);
+            for (int i = 0; i < MI; ++i) SG_MFMA(af[0][i], bf[1], acc[i][j]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) SG_MFMA(af[1][i], bf[0], acc[i][j]);
+            for (int i = 0; i < MI; ++i) SG_MFMA(af[1][i], bf[0], acc[i][j]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) SG_MFMA(af[0][i], bf[0], acc[i][j]);
+            for (int i = 0; i < MI; ++i) SG_MFMA(af[0][i], bf[0], acc[i][j]);
         }
     };
     fetch(0, ra0, rb0);
     for (int kt = 0; kt < nk; ++kt) {
         if (kt > 0) __syncthreads();                       // the previous slab's readers are done
         fix(kt, ra0, rb0);
-        sg_store<!TA>(As, ra0);
-        sg_store<TB>(Bs, rb0);
+        sg_store<!TA, NQ>(As, ra0);
+        sg_store<TB, NQ>(Bs, rb0);
         __syncthreads();
         if (kt + 1 < nk) fetch(kt + 1, ra0, rb0);
         multiply();
     }
     // ---- C tile: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = n0 + wc * 64 + j * 16 + l15;
@@ -282,7 +306,7 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
             if (a.split_out) {
                 // this lane holds 4 consecutive rows of one column: half of a k8 group -> one 8-byte store per plane
                 // (rows M .. 8 * split_k8 - 1 are the operand's zero padding)
-                const int row0 = m0 + wr * 64 + i * 16 + kq * 4;
+                const int row0 = m0 + wr * 16 * MI + i * 16 + kq * 4;
                 if (row0 < a.split_k8 * 8) {
                     const int vc = a.split_c0 + col;
                     unsigned short* vb = a.split_out + (long)b * 3 * a.split_ct * a.split_k8 * 128;
@@ -302,7 +326,7 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wr * 64 + i * 16 + kq * 4 + r;
+                const int row = m0 + wr * 16 * MI + i * 16 + kq * 4 + r;
                 if (row >= a.M) continue;
                 float* cp = C + (long)row * a.ldc + col;
                 *cp = a.beta != 0.f ? acc[i][j][r] + a.beta * *cp : acc[i][j][r];
@@ -310,15 +334,16 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
         }
 }
 
-__global__ __launch_bounds__(256) void k_gemm_split_bf16(SplitGemmArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_gemm_split_bf16(SplitGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short sg_lds[];
     const int tile = blockIdx.x;
     if (a.tA) {
-        if (a.tB) sg_body<true, true>(a, tile, sg_lds);
-        else sg_body<true, false>(a, tile, sg_lds);
+        if (a.tB) sg_body<true, true, NW>(a, tile, sg_lds);
+        else sg_body<true, false, NW>(a, tile, sg_lds);
     } else {
-        if (a.tB) sg_body<false, true>(a, tile, sg_lds);
-        else sg_body<false, false>(a, tile, sg_lds);
+        if (a.tB) sg_body<false, true, NW>(a, tile, sg_lds);
+        else sg_body<false, false, NW>(a, tile, sg_lds);
     }
 }
 
@@ -343,13 +368,16 @@ void gemm_split_bf16(Seq& q, const GemmDesc& d, int batch) {
         bgemm_group(q, &d, 1, batch, 1);
         return;
     }
-    static DynLdsOnce attr;
-    ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_gemm_split_bf16), SG_LDS_BYTES, "k_gemm_split_bf16");
+    const bool w8 = !knobs().split_gemm_w4;
+    static DynLdsOnce attr4, attr8;
+    if (w8) ensure_dyn_lds(q, attr8, reinterpret_cast<const void*>(&k_gemm_split_bf16<8>), SG_LDS_BYTES, "k_gemm_split_bf16<8>");
+    else ensure_dyn_lds(q, attr4, reinterpret_cast<const void*>(&k_gemm_split_bf16<4>), SG_LDS_BYTES, "k_gemm_split_bf16<4>");
     if (!q.ok()) return;
     SplitGemmArgs a{d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.sA, d.sB, d.sC, d.tA ? 1 : 0, d.tB ? 1 : 0, d.beta,
                     (d.N + SG_BN - 1) / SG_BN, d.split_out, d.split_ct, d.split_k8, d.split_c0, d.bias, d.act};
     const int tiles = ((d.M + SG_BM - 1) / SG_BM) * a.tilesN;
-    hipLaunchKernelGGL(k_gemm_split_bf16, dim3(tiles, batch), dim3(256), SG_LDS_BYTES, q.stream, a);
+    if (w8) hipLaunchKernelGGL(k_gemm_split_bf16<8>, dim3(tiles, batch), dim3(512), SG_LDS_BYTES, q.stream, a);
+    else hipLaunchKernelGGL(k_gemm_split_bf16<4>, dim3(tiles, batch), dim3(256), SG_LDS_BYTES, q.stream, a);
     q.check_launch("gemm_split_bf16");
 }
 
