@@ -309,22 +309,15 @@ __global__ __launch_bounds__(256) void k_bn_transform(BnTransformArgs t) {
     float* WL = lds;                         // both groups' weights
     float* XT = WL + wcnt0 + wcnt1;          // [16][cin]
     float* PT = XT + 16 * cin;               // [16][cout]
-    // (1) weights: everything in flight before anything is used
-    {
-        constexpr int WR = 4;
-        for (int e0 = 0; e0 < wcnt0 + wcnt1; e0 += 256 * WR) {
-            float w[WR];
+    // (1) weights: the first 1024 (all of them at the shapes this kernel serves most) are loaded into registers here and
+    // reach LDS only after the row and statistics loads below have been issued: one round trip for all three
+    constexpr int WR = 4;
+    const int wtot = wcnt0 + wcnt1;
+    float wreg[WR];
 #pragma unroll
-            for (int u = 0; u < WR; ++u) {
-                const int e = min(e0 + u * 256 + (int)threadIdx.x, wcnt0 + wcnt1 - 1);
-                w[u] = e < wcnt0 ? t.W[0][e] : t.W[1][e - wcnt0];
-            }
-#pragma unroll
-            for (int u = 0; u < WR; ++u) {
-                const int e = e0 + u * 256 + (int)threadIdx.x;
-                if (e < wcnt0 + wcnt1) WL[e] = w[u];
-            }
-        }
+    for (int u = 0; u < WR; ++u) {
+        const int e = min(u * 256 + (int)threadIdx.x, wtot - 1);
+        wreg[u] = e < wcnt0 ? t.W[0][e] : t.W[1][e - wcnt0];
     }
     // (2) the team's row: BatchNorm of both groups (exactly k_bn_apply_fwd's arithmetic)
     const int node = chunk * 16 + team;
@@ -380,20 +373,24 @@ __global__ __launch_bounds__(256) void k_bn_transform(BnTransformArgs t) {
             }
         }
     }
+#pragma unroll
+    for (int u = 0; u < WR; ++u) {
+        const int e = u * 256 + (int)threadIdx.x;
+        if (e < wtot) WL[e] = wreg[u];
+    }
+    for (int e = WR * 256 + (int)threadIdx.x; e < wtot; e += 256) WL[e] = e < wcnt0 ? t.W[0][e] : t.W[1][e - wcnt0];
     __syncthreads();
-    // (3) P = x W per group: one output element per thread and pass, the row broadcast from LDS
-    for (int o = threadIdx.x; o < 16 * cout; o += 256) {
-        const int r = o / cout, c = o - r * cout;
+    // (3) P = x W per group: the team keeps its row (broadcast from LDS), a lane takes every 16th output column
+    for (int c = tl; c < cout; c += 16) {
         const int g = (G == 2 && c >= t.gout.c0[1]) ? 1 : 0;
         const int win = a.g.w[g], wout = t.gout.w[g];
-        const float* xr = XT + r * cin + a.g.c0[g];
+        const float* xr = XT + team * cin + a.g.c0[g];
         const float* wc = WL + (g ? wcnt0 : 0) + (c - t.gout.c0[g]);
         float acc = 0.f;
 #pragma unroll 4
         for (int k = 0; k < win; ++k) acc = fmaf(xr[k], wc[k * wout], acc);
-        PT[o] = acc;
-        const int nd = chunk * 16 + r;
-        if (nd < a.n) t.P[((long)b * a.n + nd) * t.ldp + c] = acc;
+        PT[team * cout + c] = acc;
+        if (live) t.P[row * t.ldp + c] = acc;
     }
     if (!t.vs) return;
     __syncthreads();
