@@ -136,6 +136,7 @@ struct Knobs {
     bool no_level_fusion;  // DP_NO_LEVEL_FUSION: pooled-level GCN stacks one launch per layer
     bool no_split_gemm;    // DP_NO_SPLIT_GEMM: fp32 MFMA for every GEMM (no split-bf16 products)
     bool split_gemm_w4;    // DP_SPLIT_GEMM_W4: the 4-wave form of the split GEMM instead of the 8-wave one
+    bool no_agg_first;     // DP_NO_AGG_FIRST: every GraphConv as A (x W), also the layers that widen a lot
 };
 const Knobs& knobs();
 
@@ -278,6 +279,8 @@ void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, lo
 void axpy(Seq& q, float* y, const float* x, float a, long count);
 void mask_mul(Seq& q, const float* x, int ldx, const float* m, float* out, long rows, int w);
 void mask_axpy(Seq& q, float* dst, int ldd, const float* src, const float* m, long rows, int w);
+void gather_cols(Seq& q, const float* x0, int ld0, int w0, const float* x1, int ld1, int w1, float* out, long rows);
+void scatter_add_cols(Seq& q, const float* src, float* d0, int ld0, int w0, float* d1, int ld1, int w1, long rows);
 void zero_fill(Seq& q, void* p, size_t bytes);   // wide-store zero kernel (byte kernel for odd sizes); never a memset node
 void zero_small(Seq& q, void* p, size_t bytes);
 

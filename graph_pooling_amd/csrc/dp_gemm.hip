@@ -501,13 +501,34 @@ void bgemm_group(Seq& q, const GemmDesc* d_in, int count, int batch, int ksplit)
         q.err = DP_ERR_INVALID_ARG;
         return;
     }
+    // Big batches: a group is one launch with ONE tile shape, and a 20-row or 20-column problem in a 64 x 64 tile spends
+    // 3.2x its flops on padding — at B = 256, n = 1024 that padding, not memory, set the time of the GraphConv backward
+    // groups (363 us for [20x20x1024 TN] [1024x20x20 NT] [20x256x1024 TN] [1024x20x256 NT]).  When the group is worth
+    // more than a few launch floors it is split by shape class (short M / narrow N / the rest), one launch per class.
+    if (count > 1 && !q.pred) {
+        double flops = 0;
+        for (int i = 0; i < count; ++i) flops += 2.0 * d[i].M * d[i].N * d[i].K * batch;
+        auto cls = [](const GemmDesc& s) { return s.M <= 32 ? 0 : s.N <= 32 ? 1 : 2; };
+        bool mixed = false;
+        for (int i = 1; i < count; ++i) mixed = mixed || cls(d[i]) != cls(d[0]);
+        if (mixed && flops > 1.5e9) {
+            GemmDesc part[GEMM_GROUP_MAX];
+            for (int c = 0; c < 3; ++c) {
+                int np = 0;
+                for (int i = 0; i < count; ++i)
+                    if (cls(d[i]) == c) part[np++] = d[i];
+                if (np > 0) bgemm_group(q, part, np, batch, ksplit);
+            }
+            return;
+        }
+    }
     GemmGroupArgs g{};
     g.pred = q.pred;
     if (q.fold_zero_p && !q.pred) {      // (a predicated launch may not run at all: leave it for an unconditional one)
         g.zero_p = static_cast<uint4*>(q.fold_zero_p);
         g.zero_n16 = q.fold_zero_n16;
     }
-    int maxN = 0;
+    int maxN = 0, maxM = 0;
     for (int i = 0; i < count; ++i) {
         const GemmDesc& s = d[i];
         if (s.M <= 0 || s.N <= 0) continue;
@@ -522,6 +543,7 @@ void bgemm_group(Seq& q, const GemmDesc* d_in, int count, int batch, int ksplit)
             a.ksplit = eff < 1 ? 1 : eff;
         }
         if (s.N > maxN) maxN = s.N;
+        if (s.M > maxM) maxM = s.M;
     }
     if (g.count == 0) return;
     if (g.zero_p) q.fold_zero_p = nullptr, q.fold_zero_n16 = 0;
@@ -541,15 +563,17 @@ void bgemm_group(Seq& q, const GemmDesc* d_in, int count, int batch, int ksplit)
         // it exists to add parallelism to small-output problems, not to license bigger tiles
         return t;
     };
+    // ... and never a tile taller than the tallest problem (rows of padding are MFMA time)
     if (maxN <= 16) {
         launch_tile<64, 16, 4, 1>(q, g, batch);
     } else if (maxN <= 32) {
-        if (wgs(128, 32) >= TARGET) launch_tile<128, 32, 4, 1>(q, g, batch);
-        else if (wgs(64, 32) >= TARGET) launch_tile<64, 32, 4, 1>(q, g, batch);
+        if (maxM > 64 && wgs(128, 32) >= TARGET) launch_tile<128, 32, 4, 1>(q, g, batch);
+        else if (maxM > 32 && wgs(64, 32) >= TARGET) launch_tile<64, 32, 4, 1>(q, g, batch);
         else launch_tile<32, 32, 2, 2>(q, g, batch);
     } else {
-        if (wgs(64, 64) >= TARGET) launch_tile<64, 64, 2, 2>(q, g, batch);
-        else if (wgs(32, 64) >= TARGET) launch_tile<32, 64, 1, 4>(q, g, batch);
+        if (maxM > 32 && wgs(64, 64) >= TARGET) launch_tile<64, 64, 2, 2>(q, g, batch);
+        else if (maxM > 16 && wgs(32, 64) >= TARGET) launch_tile<32, 64, 1, 4>(q, g, batch);
+        else if (maxM > 16 && maxM <= 32) launch_tile<32, 64, 1, 4>(q, g, batch);
         else launch_tile<16, 64, 1, 4>(q, g, batch);
     }
     q.check_launch("bgemm");

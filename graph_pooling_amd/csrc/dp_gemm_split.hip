@@ -357,7 +357,7 @@ bool gemm_split_usable(const GemmDesc& d, int batch, int ksplit) {
     if ((d.bias || d.act) && d.beta != 0.f) return false;
     if (d.split_out && d.beta != 0.f) return false;
     if (d.alpha != 1.f || !(d.beta == 0.f || d.beta == 1.f)) return false;
-    if (d.M < 96 || d.N < 96 || d.K < 64) return false;       // (the rim loads also need every extent >= 4)
+    if (d.M < 96 || d.N < 96 || d.K < 48) return false;       // (the rim loads also need every extent >= 4)
     const long tiles = (long)((d.M + SG_BM - 1) / SG_BM) * ((d.N + SG_BN - 1) / SG_BN) * batch;
     return tiles >= 256;
 }

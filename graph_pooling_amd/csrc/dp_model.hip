@@ -27,6 +27,7 @@ size_t set2set_save_bytes(int B, int n, int d);
 namespace {
 
 struct LevelInfo {
+    int j;         // pooling level
     int n, G, L;
     const dp_stack_cfg* e;
     const dp_stack_cfg* a;
@@ -38,6 +39,7 @@ struct LevelInfo {
 
 LevelInfo level_info(const dp_encoder_cfg& c, int j) {
     LevelInfo li{};
+    li.j = j;
     li.n = c.n_nodes[j];
     li.e = &c.embed[j];
     li.L = li.e->n_layers;
@@ -59,6 +61,20 @@ LevelInfo level_info(const dp_encoder_cfg& c, int j) {
     return li;
 }
 
+// Association of layer l's GraphConv product.  The reference computes (A x) W (encoders.py:966-968); the plan
+// normally runs A (x W), which is cheaper when a layer narrows (DD: 89 -> 20) and lets the two stacks share a pass.
+// A layer that WIDENS a lot — the assign stack's last layer at big pooling sizes (20 -> 256: 276 joint output columns
+// against 40 input columns) — is run in the reference's own order instead: the adjacency pass carries the 40 input
+// columns (HBM-bound on A) rather than 276 (MFMA-bound), forward and backward.  Level 0 only (no adjacency gradient),
+// layers >= 1 (the input is the previous layer's output), no dropout mask on the layer.
+int layer_cin(const LevelInfo& li, int l) { return li.e->dims[l] + (li.a ? li.a->dims[l] : 0); }
+bool layer_agg_first(const LevelInfo& li, int l) {
+    if (knobs().no_agg_first || li.j != 0 || l < 1) return false;
+    if (li.e->drop_off[l] >= 0 || (li.a && li.a->drop_off[l] >= 0)) return false;
+    const int cin = layer_cin(li, l), ct = li.ctot[l];
+    return ct > 128 && ct >= 2 * cin;
+}
+
 // A bump allocator over the caller's save buffer (dry when base == nullptr).
 struct Bump {
     char* base;
@@ -75,6 +91,7 @@ struct LayerSave {
     float* Y;      // normalised pre-ReLU output of a non-last layer, joint [B, n, ctot]
     float* invn;   // [B, n, G]
     float* stats;  // [n, G, 2] (mu, rstd)
+    float* Uin;    // aggregate-first layers: A [x_e | x_a] (+ x), [B, n, cin] — the left operand of dW
 };
 struct LevelSave {
     float* Ze;
@@ -123,6 +140,7 @@ SaveLayout layout_save(const dp_encoder_cfg& c, void* base) {
             lv.layer[l].Y = (l < li.L - 1) ? b.take<float>(B * li.n * li.ctot[l]) : nullptr;
             lv.layer[l].invn = b.take<float>(B * li.n * li.G);
             lv.layer[l].stats = (l < li.L - 1) ? b.take<float>((size_t)li.n * li.G * 2) : nullptr;
+            lv.layer[l].Uin = layer_agg_first(li, l) ? b.take<float>(B * li.n * layer_cin(li, l)) : nullptr;
         }
         if (li.a) {
             lv.S = b.take<float>(B * li.n * li.K);
@@ -415,7 +433,26 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
             q.fold_zero_p = io.pack->flag;
             q.fold_zero_n16 = 16;
         }
-        if (!transformed) transform(q, c, li, lv, io, params, l, Pj, presplit ? vs : nullptr);
+        const bool agg_first = layer_agg_first(li, l);
+        if (agg_first) {
+            // (A [x_e | x_a]) W: gather the two stacks' inputs, ONE narrow pass over A, then the row-local products
+            const int cin = layer_cin(li, l), de = li.e->dims[l], da = li.a ? li.a->dims[l] : 0;
+            float* Uin = lv.layer[l].Uin;
+            gather_cols(q, lv.Ze + li.coff_e[l - 1], li.D, de, li.a ? lv.Za + li.coff_a[l - 1] : nullptr, li.Da, da, Pj,
+                        (long)B * n);
+            aggregate(q, io.adj, Pj, cin, Uin, cin, B, n, cin, false, 0.f, pk, vs, false);
+            if (add_self) axpy(q, Uin, Pj, 1.f, (long)B * n * cin);
+            GemmDesc d[2];
+            for (int gi = 0; gi < li.G; ++gi) {
+                const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
+                const int c0 = gi == 0 ? 0 : li.e->dims[l + 1], c0in = gi == 0 ? 0 : de;
+                d[gi] = GemmDesc{Uin + c0in, PW(params, st->w_off[l]), Pj + c0, nullptr, n, st->dims[l + 1], st->dims[l],
+                                 cin, st->dims[l + 1], ct, (long)n * cin, 0, (long)n * ct, false, false, 1.f, 0.f, 0};
+            }
+            bgemm_group(q, d, li.G, B);
+        } else if (!transformed) {
+            transform(q, c, li, lv, io, params, l, Pj, presplit ? vs : nullptr);
+        }
         transformed = false;
         if (l == 0 && io.pack) {
             const bool folded = q.fold_zero_p == nullptr;      // consumed by the GEMM launch
@@ -442,7 +479,10 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
         }
         const int stats_mode = (!last && bn) ? 1 : 0;
         // aggregation + GraphConv tail in one launch when the panel kernel takes the shape
-        if (!aggregate_rownorm_fwd(q, io.adj, Pj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn,
+        if (agg_first) {
+            rownorm_fwd(q, Pj, ct, nullptr, bias, g, yout, lv.layer[l].invn, stats_mode ? part : nullptr, (long)B * n, 1,
+                        stats_mode);
+        } else if (!aggregate_rownorm_fwd(q, io.adj, Pj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn,
                                    stats_mode ? part : nullptr, B, n, 1, stats_mode, pk, vs, presplit)) {
             // wide / odd shapes: plain aggregation (panel kernel with column chunks, or the generic GEMM) + row pass
             aggregate(q, io.adj, Pj, ct, Uj, ct, B, n, ct, false, 0.f, pk, vs, presplit);
@@ -458,7 +498,8 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
             // apply_bn and the NEXT layer's transform in one launch when that transform is a plain row-local product
             const RowGroups gnext = groups_of(li, l + 1);
             const float* part_r = bn ? bn_exchange(q, c, part, part_all, (size_t)B * n * li.G * 2) : nullptr;
-            bool plain_next = W == 1 && !knobs().no_level_fusion && bn_transform_supported(g, gnext, B);
+            bool plain_next = W == 1 && !knobs().no_level_fusion && bn_transform_supported(g, gnext, B) &&
+                              !layer_agg_first(li, l + 1);
             for (int gi = 0; gi < li.G; ++gi) plain_next = plain_next && !drop_mask(li, io, gi, l + 1);
             if (plain_next) {
                 const float* Wn[2] = {PW(params, li.e->w_off[l + 1]), li.a ? PW(params, li.a->w_off[l + 1]) : nullptr};
@@ -543,9 +584,34 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
         dbias.p[0] = li.e->b_off[l] >= 0 ? slabs + li.e->b_off[l] : nullptr;
         dbias.p[1] = (li.a && li.a->b_off[l] >= 0) ? slabs + li.a->b_off[l] : nullptr;
         dbias.ld[0] = dbias.ld[1] = (int)gstride;
-        const bool presplit = pk && vs && aggregate_packed_usable(io.adj, n, ct);
+        const bool agg_first = layer_agg_first(li, l) && !gr.dAdj;
+        const bool presplit = !agg_first && pk && vs && aggregate_packed_usable(io.adj, n, ct);
         rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, part2, g, dUj, ct, &dbias, B, n, !last, has_bn,
                     1, presplit ? vs : nullptr, B * W);
+        if (agg_first) {
+            // y = (A x) W: dW = (A x)^T dV with the saved A x;  d(A x) = dV W^T (row-local);  dx += A^T d(A x), one
+            // narrow pass over A
+            const int cin = layer_cin(li, l), de = li.e->dims[l], da = li.a ? li.a->dims[l] : 0;
+            const float* Uin = lv.layer[l].Uin;
+            GemmDesc d[4];
+            int nd = 0;
+            for (int gi = 0; gi < li.G; ++gi) {
+                const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
+                const int din = st->dims[l], dout = st->dims[l + 1], c0in = gi == 0 ? 0 : de;
+                d[nd++] = GemmDesc{Uin + c0in, dUj + g.c0[gi], slabs + st->w_off[l], nullptr, din, dout, n, cin, ct, dout,
+                                   (long)n * cin, (long)n * ct, gstride, true, false, 1.f, 0.f, 0, slab_stride, 0};
+                d[nd++] = GemmDesc{dUj + g.c0[gi], PW(params, st->w_off[l]), Gj + c0in, nullptr, n, din, dout, ct, dout,
+                                   cin, (long)n * ct, 0, (long)n * cin, false, true, 1.f, 0.f, 0, 0, 0, nullptr, 0, 0, 0,
+                                   1};
+            }
+            bgemm_group(q, d, nd, B, ks_level);
+            float* dxagg = dUj;                    // dV is consumed: its buffer takes A^T d(A x)
+            aggregate(q, io.adj, Gj, cin, dxagg, cin, B, n, cin, true, 0.f, pk, vs, false);
+            if (add_self) axpy(q, dxagg, Gj, 1.f, (long)B * n * cin);
+            scatter_add_cols(q, dxagg, gr.dZe + li.coff_e[l - 1], li.D, de, li.a ? gr.dZa + li.coff_a[l - 1] : nullptr,
+                             li.Da, da, (long)B * n);
+            continue;
+        }
         // G = A^T dU (+ dU)
         aggregate(q, io.adj, dUj, ct, Gj, ct, B, n, ct, true, 0.f, pk, vs, presplit);
         if (add_self) axpy(q, Gj, dUj, 1.f, (long)B * n * ct);

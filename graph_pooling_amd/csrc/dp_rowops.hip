@@ -1199,6 +1199,45 @@ void mask_axpy(Seq& q, float* dst, int ldd, const float* src, const float* m, lo
     q.check_launch("mask_axpy");
 }
 
+// ------------------------------------------------------------------ column gather / scatter-add of the two stacks
+// out[row] = [x0[row, :w0] | x1[row, :w1]]  (the inputs of an aggregate-first GraphConv layer side by side), and the
+// reverse with accumulation: d0[row, :w0] += src[row, :w0], d1[row, :w1] += src[row, w0:]
+__global__ __launch_bounds__(256) void k_gather_cols(const float* x0, int ld0, int w0, const float* x1, int ld1, int w1,
+                                                     float* out, long rows) {
+    const int w = w0 + w1;
+    const long total = rows * w;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / w;
+        const int c = (int)(e - row * w);
+        out[e] = c < w0 ? x0[row * ld0 + c] : x1[row * ld1 + (c - w0)];
+    }
+}
+__global__ __launch_bounds__(256) void k_scatter_add_cols(const float* src, float* d0, int ld0, int w0, float* d1, int ld1,
+                                                          int w1, long rows) {
+    const int w = w0 + w1;
+    const long total = rows * w;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / w;
+        const int c = (int)(e - row * w);
+        float* d = c < w0 ? d0 + row * ld0 + c : d1 + row * ld1 + (c - w0);
+        *d += src[e];
+    }
+}
+void gather_cols(Seq& q, const float* x0, int ld0, int w0, const float* x1, int ld1, int w1, float* out, long rows) {
+    if (!q.ok() || rows <= 0) return;
+    const long blocks = (rows * (w0 + w1) + 255) / 256;
+    hipLaunchKernelGGL(k_gather_cols, dim3((int)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, q.stream, x0, ld0, w0, x1,
+                       ld1, w1, out, rows);
+    q.check_launch("gather_cols");
+}
+void scatter_add_cols(Seq& q, const float* src, float* d0, int ld0, int w0, float* d1, int ld1, int w1, long rows) {
+    if (!q.ok() || rows <= 0) return;
+    const long blocks = (rows * (w0 + w1) + 255) / 256;
+    hipLaunchKernelGGL(k_scatter_add_cols, dim3((int)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, q.stream, src, d0,
+                       ld0, w0, d1, ld1, w1, rows);
+    q.check_launch("scatter_add_cols");
+}
+
 // ------------------------------------------------------------------ zero fill
 // Never hipMemsetAsync on this path.  (1) It runs its fill kernel on 256 workgroups whatever the size (17 us for the
 // 4 MB of gradient slabs); a plain wide-store kernel is 3-5x faster.  (2) A memset node captured into a hipGraph

@@ -94,6 +94,15 @@ def test_row_kernel_width_classes(H, N, ratio):
     _run(2, N, 9, H, 3, ratio, p=0.05)
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_widening_assign_layer_runs_in_the_reference_association(weighted):
+    """K = 180 clusters from 8 hidden units: the last assign layer has 188 joint output columns against 16 input
+    columns, so the plan runs it as (A x) W — encoders.py:966-968's own order, one narrow pass over A — instead of
+    A (x W) (dp_model.hip layer_agg_first).  0/1 adjacency takes the packed bf16 pass, a weighted one its fp32
+    fallback on the gathered inputs; both against the oracle, linkpred on so dS reaches the assign stack twice."""
+    _run(3, 300, 7, 8, 2, 0.6, weighted=weighted, linkpred=True, p=0.05)
+
+
 def test_forward_is_bit_reproducible_with_split_k_pooling():
     """A level of 600 nodes at B = 2 pools with split-K contractions over the node index (X' = S^T Z, A' = Tt^T S).
     Their ranges are combined in a fixed order (partial tiles + tickets, dp_gemm.hip), not with float atomics, so the

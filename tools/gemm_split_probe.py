@@ -45,3 +45,5 @@ run("S dA'^T      NT 1024x256x256", 1024, 256, 256, 0, 1)
 run("logits       NT 1024x256x296", 1024, 256, 296, 0, 1)
 run("dZa          NN 1024x296x256", 1024, 296, 256, 0, 0)
 run("dWp          TN 256x296x1024", 256, 296, 1024, 1, 0)
+run("dS = Z dX'^T NT 1024x256x60", 1024, 256, 60, 0, 1)
+run("A'=T^T S lvl1 TN 256x256x40?", 256, 256, 40, 0, 1)
