@@ -136,6 +136,7 @@ struct Knobs {
     bool no_level_fusion;  // DP_NO_LEVEL_FUSION: pooled-level GCN stacks one launch per layer
     bool no_split_gemm;    // DP_NO_SPLIT_GEMM: fp32 MFMA for every GEMM (no split-bf16 products)
     bool split_gemm_w4;    // DP_SPLIT_GEMM_W4: the 4-wave form of the split GEMM instead of the 8-wave one
+    bool no_row_quads;     // DP_NO_ROW_QUADS: wide row kernels with 4-byte lanes (the pre-quad form)
     bool no_agg_first;     // DP_NO_AGG_FIRST: every GraphConv as A (x W), also the layers that widen a lot
 };
 const Knobs& knobs();

@@ -511,7 +511,7 @@ void bgemm_group(Seq& q, const GemmDesc* d_in, int count, int batch, int ksplit)
         auto cls = [](const GemmDesc& s) { return s.M <= 32 ? 0 : s.N <= 32 ? 1 : 2; };
         bool mixed = false;
         for (int i = 1; i < count; ++i) mixed = mixed || cls(d[i]) != cls(d[0]);
-        if (mixed && flops > 1.5e9) {
+        if (mixed && flops > 0.5e9) {
             GemmDesc part[GEMM_GROUP_MAX];
             for (int c = 0; c < 3; ++c) {
                 int np = 0;

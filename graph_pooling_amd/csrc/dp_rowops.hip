@@ -8,6 +8,12 @@ namespace dp {
 #define L2_EPS 1e-12f
 #define BN_EPS 1e-5f
 
+// Wide rows (a group wider than 128 columns, every group width a multiple of 4): the lane's share of a row moves as
+// 16-byte quads — lane tl holds quads tl, tl + 16, ... — a quarter of the memory instructions of the 4-byte form,
+// which set the pace of these kernels at 256-column rows (k_rownorm_fwd 330 us for 580 MB at the ER shape).  Global
+// dwordx4 accesses need only dword alignment on gfx9 under HSA, so row starts need not be 16-byte aligned.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
 __device__ inline float team_sum(float v) {
     return row16_sum(v);
 }
@@ -15,6 +21,12 @@ __device__ inline float team_max(float v) {
     return row16_max(v);
 }
 
+static inline bool row_quads_ok(const RowGroups& g) {
+    if (knobs().no_row_quads) return false;
+    for (int i = 0; i < g.G; ++i)
+        if (g.w[i] < 4 || (g.w[i] & 3)) return false;
+    return true;
+}
 static inline int team_grid(long items) {
     long blocks = (items + 15) / 16;
     if (blocks > 4096) blocks = 4096;
@@ -41,7 +53,7 @@ struct RownormFwdArgs {
 // NK > 0: group widths <= 16 NK — the row (+ add_self operand, + bias) is read ONCE into registers; the three passes
 // of the generic form (norm, write, statistics) re-read it from memory: 342 us against ~150 for the 276-wide assign
 // layer at the ER shape.
-template <int NK>
+template <int NK, bool Q4 = false>
 __global__ __launch_bounds__(256) void k_rownorm_fwd(RownormFwdArgs a) {
     const int tl = threadIdx.x & 15;
     const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -55,6 +67,57 @@ __global__ __launch_bounds__(256) void k_rownorm_fwd(RownormFwdArgs a) {
         const float* p = a.P ? a.P + row * a.ldu + c0 : nullptr;
         const float* bias = a.bias.p[g];
         float* y = a.yout.p[g] + row * a.yout.ld[g];
+        if constexpr (Q4) {
+            constexpr int NQ = NK > 0 ? NK : 1;      // quads per lane
+            const int nq = w >> 2;
+            f4u v[NQ];
+            const float* pp = p ? p : u;             // valid addresses either way: no branch around a load
+            const float* bb = bias ? bias : u;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const int qd = min(tl + 16 * k, nq - 1) * 4;
+                const f4u t0 = *reinterpret_cast<const f4u*>(u + qd);
+                const f4u t1 = *reinterpret_cast<const f4u*>(pp + qd);
+                const f4u t2 = *reinterpret_cast<const f4u*>(bb + qd);
+                f4u t = t0;
+                if (p) t += t1;
+                if (bias) t += t2;
+                v[k] = tl + 16 * k < nq ? t : (f4u){0.f, 0.f, 0.f, 0.f};
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) ss += v[k][0] * v[k][0] + v[k][1] * v[k][1] + v[k][2] * v[k][2] + v[k][3] * v[k][3];
+            ss = team_sum(ss);
+            const float inv = a.normalize ? 1.f / fmaxf(sqrtf(ss), L2_EPS) : 1.f;
+            float s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                v[k] *= inv;
+                if (tl + 16 * k < nq) *reinterpret_cast<f4u*>(y + (tl + 16 * k) * 4) = v[k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s1 += a.stats_mode == 1 ? fmaxf(v[k][j], 0.f) : v[k][j];
+            }
+            if (tl == 0 && a.invn) a.invn[it] = inv;
+            if (a.stats_mode && a.part) {
+                s1 = team_sum(s1);
+                const float mean = s1 / (float)w;
+                float m2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < NQ; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = a.stats_mode == 1 ? fmaxf(v[k][j], 0.f) : v[k][j];
+                        t -= mean;
+                        m2 += tl + 16 * k < nq ? t * t : 0.f;
+                    }
+                m2 = team_sum(m2);
+                if (tl == 0) {
+                    a.part[it * 2 + 0] = mean;
+                    a.part[it * 2 + 1] = m2;
+                }
+            }
+            continue;
+        }
         if (NK > 0) {
             constexpr int NKK = NK > 0 ? NK : 1;
             float v[NKK];
@@ -145,6 +208,13 @@ void rownorm_fwd(Seq& q, const float* U, int ldu, const float* P, GroupCPtrs bia
     RownormFwdArgs a{U, ldu, P, bias, g, yout, invn, part, rows, normalize, stats_mode};
     const int maxw = g.G == 2 && g.w[1] > g.w[0] ? g.w[1] : g.w[0];
     const dim3 grid(team_grid(rows * g.G));
+    if (maxw > 128 && maxw <= 512 && row_quads_ok(g)) {
+        if (maxw <= 256) hipLaunchKernelGGL((k_rownorm_fwd<4, true>), grid, dim3(256), 0, q.stream, a);
+        else if (maxw <= 320) hipLaunchKernelGGL((k_rownorm_fwd<5, true>), grid, dim3(256), 0, q.stream, a);
+        else hipLaunchKernelGGL((k_rownorm_fwd<8, true>), grid, dim3(256), 0, q.stream, a);
+        q.check_launch("rownorm_fwd");
+        return;
+    }
     if (maxw <= 32) hipLaunchKernelGGL(k_rownorm_fwd<2>, grid, dim3(256), 0, q.stream, a);
     else if (maxw <= 64) hipLaunchKernelGGL(k_rownorm_fwd<4>, grid, dim3(256), 0, q.stream, a);
     else if (maxw <= 128) hipLaunchKernelGGL(k_rownorm_fwd<8>, grid, dim3(256), 0, q.stream, a);
@@ -518,7 +588,7 @@ struct RownormBwdArgs {
 // grid (chunks, B): a workgroup owns a contiguous chunk of rows of ONE graph, so the column sums of dU
 // (the bias gradients, db = sum_rows dU) can be accumulated in LDS and leave as one partial per workgroup.
 // NK > 0: group widths up to 16 NK, the row's operands live in registers (see the item loop); NK == 0: any width.
-template <int NK>
+template <int NK, bool Q4 = false>
 __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float colsum[];
     const int tl = threadIdx.x & 15;
@@ -543,6 +613,73 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
         const int w = a.g.w[g];
         const float* dx = a.dx.p[g] + row * a.dx.ld[g];
         const float* y = a.y.p[g] + row * a.y.ld[g];
+        if constexpr (Q4) {
+            // the NK > 0 form below with 16-byte quads (NK = quads per lane)
+            constexpr int NQ = NK > 0 ? NK : 1;
+            const int nq = w >> 2;
+            const float* xh = a.has_bn ? a.xhat.p[g] + row * a.xhat.ld[g] : dx;
+            f4u dxv[NQ], yv[NQ], xhv[NQ];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const int qd = min(tl + 16 * k, nq - 1) * 4;
+                dxv[k] = *reinterpret_cast<const f4u*>(dx + qd);
+                yv[k] = *reinterpret_cast<const f4u*>(y + qd);
+                xhv[k] = *reinterpret_cast<const f4u*>(xh + qd);
+            }
+            const float rstd_l = (a.has_bn ? a.stats : dx)[a.has_bn ? ((long)node * a.g.G + g) * 2 + 1 : 0];
+            const float inv_l = (a.normalize ? a.invn : dx)[a.normalize ? row * a.g.G + g : 0];
+            float s0 = 0.f, s1 = 0.f;
+            {
+                const long pstride = (long)a.n * a.g.G * 2;
+                const float* p = (a.has_bn ? a.part2 : dx) + (a.has_bn ? ((long)node * a.g.G + g) * 2 : 0);
+                const int nb = (a.has_bn && !a.means_ready) ? a.Bs : 0;
+                for (int bb = tl; bb < nb; bb += 16) {
+                    s0 += p[bb * pstride];
+                    s1 += p[bb * pstride + 1];
+                }
+                if (a.means_ready) {
+                    s0 = p[0];
+                    s1 = p[1];
+                }
+            }
+            const float cnt = (float)a.Bs * (float)w;
+            const float rstd = a.has_bn ? rstd_l : 1.f;
+            const float m0 = !a.has_bn ? 0.f : a.means_ready ? s0 : team_sum(s0) / cnt;
+            const float m1 = !a.has_bn ? 0.f : a.means_ready ? s1 : team_sum(s1) / cnt;
+            const float inv = a.normalize ? inv_l : 1.f;
+            const bool project = a.normalize && (inv < 1.0f / L2_EPS);
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float d = dxv[k][j];
+                    if (a.has_bn) d = rstd * (d - m0 - xhv[k][j] * m1);
+                    if (a.has_relu) d = yv[k][j] > 0.f ? d : 0.f;
+                    if (tl + 16 * k >= nq) d = 0.f;
+                    dxv[k][j] = d;
+                    dot += d * yv[k][j];
+                }
+            dot = team_sum(dot);
+            float* du = a.dU + row * a.ldu + a.g.c0[g];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const int c = (tl + 16 * k) * 4;
+                if (tl + 16 * k < nq) {
+                    f4u v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = project ? inv * (dxv[k][j] - yv[k][j] * dot) : inv * dxv[k][j];
+                    *reinterpret_cast<f4u*>(du + c) = v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (a.want_bias) mysum[a.g.c0[g] + c + j] += v[j];
+                        if (a.vs) tile8[(node - r0) * ct + a.g.c0[g] + c + j] = v[j];
+                    }
+                }
+            }
+            continue;
+        }
         if (NK > 0) {
             // ---- every global read of the item goes out here, clamped and unpredicated: the row is one memory
             // round trip instead of five dependent ones (statistics -> row -> row again)
@@ -729,6 +866,13 @@ void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const flo
     const int maxw = g.G == 2 && g.w[1] > g.w[0] ? g.w[1] : g.w[0];
     const dim3 grid(rownorm_bwd_chunks(n), B);
     const size_t lds = ((want ? 16 : 0) + (vs ? 8 : 0)) * ct * sizeof(float);
+    if (maxw > 128 && maxw <= 512 && row_quads_ok(g)) {
+        if (maxw <= 256) hipLaunchKernelGGL((k_rownorm_bwd<4, true>), grid, dim3(256), lds, q.stream, a);
+        else if (maxw <= 320) hipLaunchKernelGGL((k_rownorm_bwd<5, true>), grid, dim3(256), lds, q.stream, a);
+        else hipLaunchKernelGGL((k_rownorm_bwd<8, true>), grid, dim3(256), lds, q.stream, a);
+        q.check_launch("rownorm_bwd");
+        return;
+    }
     if (maxw <= 32) hipLaunchKernelGGL(k_rownorm_bwd<2>, grid, dim3(256), lds, q.stream, a);
     else if (maxw <= 64) hipLaunchKernelGGL(k_rownorm_bwd<4>, grid, dim3(256), lds, q.stream, a);
     else if (maxw <= 128) hipLaunchKernelGGL(k_rownorm_bwd<8>, grid, dim3(256), lds, q.stream, a);
@@ -825,7 +969,7 @@ struct SoftmaxFwdArgs {
     long zero_n16;
 };
 // NK > 0: K <= 16 NK, the row's logits are read once and its exponentials computed once, both kept in registers.
-template <int NK>
+template <int NK, bool Q4 = false>
 __global__ __launch_bounds__(256) void k_softmax_mask_fwd_plan(SoftmaxFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];      // [16][K]
     const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
@@ -842,7 +986,39 @@ __global__ __launch_bounds__(256) void k_softmax_mask_fwd_plan(SoftmaxFwdArgs a)
         const float* l = a.logits + row * a.ldl;
         float* s = a.S + row * a.lds;
         float* s2 = a.S2 ? a.S2 + row * a.lds : nullptr;
-        if (NK > 0) {
+        if constexpr (Q4) {
+            constexpr int NQ = NK > 0 ? NK : 1;       // quads per lane, K % 4 == 0
+            const int nq = K >> 2;
+            f4u lv[NQ];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) lv[k] = *reinterpret_cast<const f4u*>(l + min(tl + 16 * k, nq - 1) * 4);
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) m = fmaxf(fmaxf(m, fmaxf(lv[k][0], lv[k][1])), fmaxf(lv[k][2], lv[k][3]));
+            m = team_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lv[k][j] = expf(lv[k][j] - m);
+                    sum += (tl + 16 * k < nq) ? lv[k][j] : 0.f;
+                }
+            sum = team_sum(sum);
+            const float r = 1.f / sum;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const int c = (tl + 16 * k) * 4;
+                if (tl + 16 * k < nq) {
+                    f4u v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = valid ? lv[k][j] * r : 0.f;
+                    *reinterpret_cast<f4u*>(s + c) = v;
+                    if (s2) *reinterpret_cast<f4u*>(s2 + c) = v;
+                    *reinterpret_cast<f4u*>(tile + team * K + c) = v;
+                }
+            }
+        } else if (NK > 0) {
             constexpr int NKK = NK > 0 ? NK : 1;
             float lv[NKK];
 #pragma unroll
@@ -928,6 +1104,11 @@ void softmax_mask_fwd(Seq& q, const float* logits, int ldl, float* S, int lds, c
                          (uint4*)zero_p, (long)(zero_bytes / 16)};
         const dim3 grid((n + 15) / 16, B);
         const size_t sm = (size_t)16 * K * sizeof(float);
+        if (K > 128 && K <= 512 && (K & 3) == 0 && !knobs().no_row_quads) {
+            if (K <= 256) hipLaunchKernelGGL((k_softmax_mask_fwd_plan<4, true>), grid, dim3(256), sm, q.stream, a);
+            else if (K <= 320) hipLaunchKernelGGL((k_softmax_mask_fwd_plan<5, true>), grid, dim3(256), sm, q.stream, a);
+            else hipLaunchKernelGGL((k_softmax_mask_fwd_plan<8, true>), grid, dim3(256), sm, q.stream, a);
+        } else
         if (K <= 64) hipLaunchKernelGGL(k_softmax_mask_fwd_plan<4>, grid, dim3(256), sm, q.stream, a);
         else if (K <= 128) hipLaunchKernelGGL(k_softmax_mask_fwd_plan<8>, grid, dim3(256), sm, q.stream, a);
         else if (K <= 256) hipLaunchKernelGGL(k_softmax_mask_fwd_plan<16>, grid, dim3(256), sm, q.stream, a);
@@ -961,7 +1142,7 @@ __global__ __launch_bounds__(256) void k_softmax_mask_bwd(const float* S, int ld
 // gradient) of its rows to the graph's slab row with one float atomic per column and workgroup.
 // NK > 0: K <= 16 NK and RW of a team's four rows have every operand in flight at once and kept in registers (one
 // memory round trip per RW rows; row after row with two passes each it was eight).  NK == 0: any K.
-template <int NK, int RW>
+template <int NK, int RW, bool Q4 = false>
 __global__ __launch_bounds__(256) void k_softmax_mask_bwd_plan(const float* S, int lds, const float* dS, int ldds,
                                                                float* dl, int ldl, int n, int K, float* dbias,
                                                                long dbias_stride, const float* dS2) {
@@ -971,7 +1152,42 @@ __global__ __launch_bounds__(256) void k_softmax_mask_bwd_plan(const float* S, i
     float* mysum = colsum + team * K;
     for (int c = tl; c < K; c += 16) mysum[c] = 0.f;
     const int r0 = blockIdx.x * 64, r1 = min(n, r0 + 64);
-    if (NK > 0) {
+    if constexpr (Q4) {
+        constexpr int NQ = NK > 0 ? NK : 1;           // quads per lane, K % 4 == 0; one row per team and pass
+        const int nq = K >> 2;
+        const float* d2base = dS2 ? dS2 : dS;
+        for (int node = r0 + team; node < r1; node += 16) {
+            const long row = (long)b * n + node;
+            f4u sv[NQ], dv[NQ];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const int qd = min(tl + 16 * k, nq - 1) * 4;
+                sv[k] = *reinterpret_cast<const f4u*>(S + row * lds + qd);
+                const f4u x = *reinterpret_cast<const f4u*>(dS + row * ldds + qd);
+                const f4u y = *reinterpret_cast<const f4u*>(d2base + row * ldds + qd);
+                dv[k] = dS2 ? x + y : x;
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dot += (tl + 16 * k < nq) ? sv[k][j] * dv[k][j] : 0.f;
+            dot = team_sum(dot);
+            float* o = dl + row * ldl;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const int c = (tl + 16 * k) * 4;
+                if (tl + 16 * k < nq) {
+                    f4u v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = sv[k][j] * (dv[k][j] - dot);
+                    *reinterpret_cast<f4u*>(o + c) = v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mysum[c + j] += v[j];
+                }
+            }
+        }
+    } else if (NK > 0) {
         constexpr int NKK = NK > 0 ? NK : 1;
         for (int base = r0 + team; base < r1; base += 16 * RW) {
             float sv[RW][NKK], dv[RW][NKK];
@@ -1044,6 +1260,14 @@ void softmax_mask_bwd(Seq& q, const float* S, int lds, const float* dS, int ldds
 #define DP_SMB(NK, RW)                                                                                            \
     hipLaunchKernelGGL((k_softmax_mask_bwd_plan<NK, RW>), grid, dim3(256), sm, q.stream, S, lds, dS, ldds, dlogits, \
                        ldl, n, K, dbias, dbias_stride, dS2)
+        if (K > 128 && K <= 512 && (K & 3) == 0 && !knobs().no_row_quads) {
+            if (K <= 256) hipLaunchKernelGGL((k_softmax_mask_bwd_plan<4, 1, true>), grid, dim3(256), sm, q.stream, S, lds,
+                                             dS, ldds, dlogits, ldl, n, K, dbias, dbias_stride, dS2);
+            else if (K <= 320) hipLaunchKernelGGL((k_softmax_mask_bwd_plan<5, 1, true>), grid, dim3(256), sm, q.stream, S,
+                                                  lds, dS, ldds, dlogits, ldl, n, K, dbias, dbias_stride, dS2);
+            else hipLaunchKernelGGL((k_softmax_mask_bwd_plan<8, 1, true>), grid, dim3(256), sm, q.stream, S, lds, dS, ldds,
+                                    dlogits, ldl, n, K, dbias, dbias_stride, dS2);
+        } else
         if (K <= 64) DP_SMB(4, 4);
         else if (K <= 128) DP_SMB(8, 2);
         else if (K <= 256) DP_SMB(16, 1);

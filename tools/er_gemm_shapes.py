@@ -51,8 +51,31 @@ def join(err_path, trace_path):
         print(f"{us:8.1f} us  x{cnt:<2d} {us / cnt:7.1f} each  {tile:16s} {head:24s} {shape}")
 
 
+def kernels(trace_path):
+    """Per-kernel totals of the LAST third of the trace's dispatches (= the third of three identical eager steps)."""
+    rows = list(csv.DictReader(open(trace_path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # the three steps launch the same sequence: find the period from the end
+    names = [r["Kernel_Name"] for r in rows]
+    per = next(p for p in range(20, len(names) // 2) if names[-p:] == names[-2 * p:-p])
+    last = rows[-per:]
+    agg = {}
+    for r in last:
+        k = r["Kernel_Name"].replace("void dp::", "").replace("(anonymous namespace)::", "")[:64]
+        a = agg.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot = sum(v[1] for v in agg.values())
+    span = (int(last[-1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])) / 1e3
+    print(f"{per} launches in the step; kernel time {tot:.0f} us, first start to last end {span:.0f} us")
+    for k, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{us:8.1f} us  x{cnt:<3d} {us / cnt:7.1f} each  {k}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
+    elif sys.argv[1] == "kernels":
+        kernels(sys.argv[2])
     else:
         join(sys.argv[2], sys.argv[3])
