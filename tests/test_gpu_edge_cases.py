@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from graph_pooling_amd.encoders import SoftPoolingGcnEncoder
+from graph_pooling_amd.encoders import GcnEncoderGraph, SoftPoolingGcnEncoder
 from oracle import diffpool_oracle as O
 from tests.parity import close, grads_close, gpu_winners
 
@@ -101,6 +101,28 @@ def test_widening_assign_layer_runs_in_the_reference_association(weighted):
     A (x W) (dp_model.hip layer_agg_first).  0/1 adjacency takes the packed bf16 pass, a weighted one its fp32
     fallback on the gathered inputs; both against the oracle, linkpred on so dS reaches the assign stack twice."""
     _run(3, 300, 7, 8, 2, 0.6, weighted=weighted, linkpred=True, p=0.05)
+
+
+@pytest.mark.parametrize("concat", [True, False])
+def test_widening_last_layer_of_the_base_encoder(concat):
+    """GcnEncoderGraph with embedding_dim 160 from 16 hidden units: conv_last widens 10x and runs as (A x [+ x]) W
+    (concat=False is add_self=True, encoders.py:1003); against the oracle's base_forward."""
+    B, N, F_, H, E, Cc = 3, 200, 7, 16, 160, 3
+    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=N, p=0.05, seed=11, n_classes=Cc)
+    model = GcnEncoderGraph(F_, H, E, Cc, 3, pred_hidden_dims=[20], concat=concat, bn=True)
+    params = O.init_params({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=11, bias_scale=0.1)
+    model.load_state_dict(params)
+    model = model.cuda()
+    ypred = model(x.cuda(), adj.cuda(), nn_)
+    loss = model.loss(ypred, label.cuda())
+    loss.backward()
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    yo = O.base_forward(P, x, adj, n_pred_hidden=1, bn=True, concat=concat)
+    lo = torch.nn.functional.cross_entropy(yo, label)
+    lo.backward()
+    close(ypred, yo)
+    close(loss, lo, 1e-4, 1e-6)
+    grads_close(model, {k: v.grad for k, v in P.items()})
 
 
 def test_forward_is_bit_reproducible_with_split_k_pooling():
