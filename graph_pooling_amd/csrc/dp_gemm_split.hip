@@ -140,6 +140,24 @@ __device__ __forceinline__ void sg_split(float v, unsigned short& h, unsigned sh
     l = __builtin_bit_cast(unsigned short, lb);
 }
 
+// Two values at once, the way the hardware converts them: v_cvt_pk_bf16_f32 rounds a PAIR into one packed word (the
+// LDS image wants consecutive k packed anyway), the two halves widen back with one shift and one mask, and the
+// residuals of a pair are one v_pk_add_f32.  9 vector instructions per pair; the element-wise form above compiled to
+// 7-8 per ELEMENT plus the packing (cvt_pk with an unused half, v_or_b32_sdwa to assemble the word).
+typedef float sg_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sg_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sg_split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    sg_f32x2 v = {a, b};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, sg_bf16x2));
+    sg_f32x2 hv = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    v -= hv;
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(v, sg_bf16x2));
+    sg_f32x2 mv = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    v -= mv;
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(v, sg_bf16x2));
+}
+typedef unsigned sg_u32x2 __attribute__((ext_vector_type(2)));
+
 // ---- registers -> LDS planes [plane][row][k]
 template <bool KC, int NQ>
 __device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const SgRegs<NQ>& s) {
@@ -150,47 +168,38 @@ __device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const
         for (int i = 0; i < NQ; ++i) {
             const int slot = t + NT * i;
             const int r = slot >> 3, k = (slot & 7) * 4;
-            sg_u16x4 h, m, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                unsigned short hh, mm, ll;
-                sg_split(s.q[i][j], hh, mm, ll);
-                h[j] = hh; m[j] = mm; l[j] = ll;
-            }
+            unsigned h0, m0, l0, h1, m1, l1;
+            sg_split_pair(s.q[i][0], s.q[i][1], h0, m0, l0);
+            sg_split_pair(s.q[i][2], s.q[i][3], h1, m1, l1);
             unsigned short* d = img + r * SG_LDK + k;
-            *reinterpret_cast<sg_u16x4*>(d) = h;
-            *reinterpret_cast<sg_u16x4*>(d + SG_PLANE) = m;
-            *reinterpret_cast<sg_u16x4*>(d + 2 * SG_PLANE) = l;
+            *reinterpret_cast<sg_u32x2*>(d) = (sg_u32x2){h0, h1};
+            *reinterpret_cast<sg_u32x2*>(d + SG_PLANE) = (sg_u32x2){m0, m1};
+            *reinterpret_cast<sg_u32x2*>(d + 2 * SG_PLANE) = (sg_u32x2){l0, l1};
         }
     } else if (NQ == 4) {
         // q[i][j] = element (row rb*4 + j, k kb*4 + i): write row j's four k values as one quad
         const int r = (t >> 3) * 4, k = (t & 7) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            sg_u16x4 h, m, l;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                unsigned short hh, mm, ll;
-                sg_split(s.q[i][j], hh, mm, ll);
-                h[i] = hh; m[i] = mm; l[i] = ll;
-            }
+            unsigned h0, m0, l0, h1, m1, l1;
+            sg_split_pair(s.q[0][j], s.q[1][j], h0, m0, l0);
+            sg_split_pair(s.q[2][j], s.q[3][j], h1, m1, l1);
             unsigned short* d = img + (r + j) * SG_LDK + k;
-            *reinterpret_cast<sg_u16x4*>(d) = h;
-            *reinterpret_cast<sg_u16x4*>(d + SG_PLANE) = m;
-            *reinterpret_cast<sg_u16x4*>(d + 2 * SG_PLANE) = l;
+            *reinterpret_cast<sg_u32x2*>(d) = (sg_u32x2){h0, h1};
+            *reinterpret_cast<sg_u32x2*>(d + SG_PLANE) = (sg_u32x2){m0, m1};
+            *reinterpret_cast<sg_u32x2*>(d + 2 * SG_PLANE) = (sg_u32x2){l0, l1};
         }
     } else {
         // q[i][j] = element (row rb*4 + j, k kb*2 + i): row j's two k values as one 4-byte store
         const int r = (t >> 4) * 4, k = (t & 15) * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            unsigned short h0, m0, l0, h1, m1, l1;
-            sg_split(s.q[0][j], h0, m0, l0);
-            sg_split(s.q[NQ - 1][j], h1, m1, l1);
+            unsigned h, m, l;
+            sg_split_pair(s.q[0][j], s.q[NQ - 1][j], h, m, l);
             unsigned short* d = img + (r + j) * SG_LDK + k;
-            *reinterpret_cast<unsigned*>(d) = (unsigned)h0 | ((unsigned)h1 << 16);
-            *reinterpret_cast<unsigned*>(d + SG_PLANE) = (unsigned)m0 | ((unsigned)m1 << 16);
-            *reinterpret_cast<unsigned*>(d + 2 * SG_PLANE) = (unsigned)l0 | ((unsigned)l1 << 16);
+            *reinterpret_cast<unsigned*>(d) = h;
+            *reinterpret_cast<unsigned*>(d + SG_PLANE) = m;
+            *reinterpret_cast<unsigned*>(d + 2 * SG_PLANE) = l;
         }
     }
 }
