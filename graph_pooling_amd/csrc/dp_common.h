@@ -137,6 +137,7 @@ struct Knobs {
     bool no_split_gemm;    // DP_NO_SPLIT_GEMM: fp32 MFMA for every GEMM (no split-bf16 products)
     bool split_gemm_w4;    // DP_SPLIT_GEMM_W4: the 4-wave form of the split GEMM instead of the 8-wave one
     bool no_row_quads;     // DP_NO_ROW_QUADS: wide row kernels with 4-byte lanes (the pre-quad form)
+    bool no_rowpart_hook;  // DP_NO_ROWPART_HOOK: BatchNorm-backward partials in a launch of their own
     bool no_agg_first;     // DP_NO_AGG_FIRST: every GraphConv as A (x W), also the layers that widen a lot
 };
 const Knobs& knobs();
@@ -183,7 +184,16 @@ struct GemmDesc {
     // writes C.  Bit-reproducible, one launch, no workgroup ever waits for another.
     float* fix_part;
     int* fix_cnt;
+    // optional row partials of the FINAL C (after beta / accumulation): part[((b * M + row) * rp_G + rp_g) * 2 + {0, 1}] =
+    // (sum_c C[row, c], sum_c C[row, c] * xhat[row, c]) — the BatchNorm-backward partials of the layer whose gradient
+    // this product completes (k_bn_bwd_partials without its launch).  Needs N <= 32, nosplit, no atomic
+    // (gemm_rowpart_ok); xhat rows are rp_ldx apart, graphs M * rp_ldx.
+    const float* rp_xhat;
+    int rp_ldx;
+    float* rp_part;
+    int rp_G, rp_g;
 };
+inline bool gemm_rowpart_ok(int N) { return N >= 1 && N <= 32; }
 // ints of fix_cnt a problem needs (an upper bound over every tile shape the launcher may pick)
 inline size_t gemm_fix_counters(int batch, int M, int N) {
     return (size_t)batch * ((M + 15) / 16) * ((N + 15) / 16);

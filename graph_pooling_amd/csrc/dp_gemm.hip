@@ -46,6 +46,10 @@ struct GemmArgs {
     int split_ct, split_k8, split_c0;
     float* fix_part;                      // deterministic split-K (see GemmDesc)
     int* fix_cnt;
+    const float* rp_xhat;                 // row partials of the final C (see GemmDesc)
+    int rp_ldx;
+    float* rp_part;
+    int rp_G, rp_g;
     int stamp_slot;   // diagnostic build only
 };
 
@@ -235,6 +239,20 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, int ks, float* lds
             }
     }
 
+    // row-partial hook: the xhat tile is asked for with the other epilogue operands (wave column 0 holds every column)
+    float xh[MI][NI][4];
+    if (a.rp_part) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = min(n0 + wc * WN + j * 16 + l15, a.N - 1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xh[i][j][r] = a.rp_xhat[((long)b * a.M + min(m0 + wr * WM + i * 16 + l4 * 4 + r, a.M - 1)) * a.rp_ldx + col];
+        }
+    }
+
     const int nk = kend > kbeg ? (kend - kbeg + KT - 1) / KT : 0;
     // Two K slabs of each operand are in flight ahead of the multiply.  (Four -- every slab of the 1-4 slab ranges the
     // model hands over -- measured no better: DD 0.376 vs 0.371 ms per step, and 184 VGPRs on the 128x32 tile.)
@@ -346,6 +364,11 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, int ks, float* lds
                 for (int j = 0; j < NI; ++j) acc[i][j] += t[i][j];
         }
     }
+    float rp0[MI][4], rp1[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rp0[i][r] = rp1[i][r] = 0.f;
     // C/D map of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -386,8 +409,27 @@ __device__ inline void gemm_body(const GemmArgs& a, int tile, int ks, float* lds
                 if (rmw) v += a.beta * cold[i][j][r];
                 if (a.act == 1) v = fmaxf(v, 0.f);
                 *cp = v;
+                if (a.rp_part) {
+                    rp0[i][r] += v;
+                    rp1[i][r] += v * xh[i][j][r];
+                }
             }
         }
+    if (a.rp_part) {
+        // a row's columns all sit in wave column 0 (N <= WN, checked on the host): 16 lanes per row, no LDS
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s0 = row16_sum(rp0[i][r]), s1 = row16_sum(rp1[i][r]);
+                const int row = m0 + wr * WM + i * 16 + l4 * 4 + r;
+                if (wc == 0 && tn == 0 && l15 == 0 && row < a.M) {
+                    float* pp = a.rp_part + (((long)b * a.M + row) * a.rp_G + a.rp_g) * 2;
+                    pp[0] = s0;
+                    pp[1] = s1;
+                }
+            }
+    }
     GEMM_STAMP(a.stamp_slot, 6);
 }
 
@@ -529,13 +571,23 @@ void bgemm_group(Seq& q, const GemmDesc* d_in, int count, int batch, int ksplit)
         g.zero_n16 = q.fold_zero_n16;
     }
     int maxN = 0, maxM = 0;
+    bool hooked = false;      // a problem carries the row-partial hook: its row must stay inside ONE wave (WN >= 32)
     for (int i = 0; i < count; ++i) {
         const GemmDesc& s = d[i];
         if (s.M <= 0 || s.N <= 0) continue;
         GemmArgs& a = g.p[g.count++];
         a = GemmArgs{s.A, s.B, s.C, s.bias, s.M, s.N, s.K, s.lda, s.ldb, s.ldc, s.sA, s.sB, s.sC, s.alpha, s.beta,
                      s.act, 0, s.tA ? 1 : 0, s.tB ? 1 : 0, s.nosplit ? 1 : ksplit, ksplit, s.sK, s.atomic,
-                     s.split_out, s.split_ct, s.split_k8, s.split_c0, s.fix_part, s.fix_cnt};
+                     s.split_out, s.split_ct, s.split_k8, s.split_c0, s.fix_part, s.fix_cnt, s.rp_xhat, s.rp_ldx,
+                     s.rp_part, s.rp_G, s.rp_g};
+        if (s.rp_part) {
+            if (!gemm_rowpart_ok(s.N) || s.atomic || !s.nosplit || s.split_out || s.fix_part) {
+                set_error("bgemm_group: row-partial hook on an unsupported problem (N=%d)", s.N);
+                q.err = DP_ERR_INVALID_ARG;
+                return;
+            }
+            hooked = true;
+        }
         if (a.ksplit > 1 && a.sK == 0) {
             // ranges that start past K have nothing to add to a shared C (atomic or ticket combine): not launched
             const int kchunk = ((a.K + a.ksplit * KT - 1) / (a.ksplit * KT)) * KT;
@@ -568,10 +620,10 @@ void bgemm_group(Seq& q, const GemmDesc* d_in, int count, int batch, int ksplit)
         launch_tile<64, 16, 4, 1>(q, g, batch);
     } else if (maxN <= 32) {
         if (maxM > 64 && wgs(128, 32) >= TARGET) launch_tile<128, 32, 4, 1>(q, g, batch);
-        else if (maxM > 32 && wgs(64, 32) >= TARGET) launch_tile<64, 32, 4, 1>(q, g, batch);
+        else if (hooked || (maxM > 32 && wgs(64, 32) >= TARGET)) launch_tile<64, 32, 4, 1>(q, g, batch);
         else launch_tile<32, 32, 2, 2>(q, g, batch);
     } else {
-        if (maxM > 32 && wgs(64, 64) >= TARGET) launch_tile<64, 64, 2, 2>(q, g, batch);
+        if (hooked || (maxM > 32 && wgs(64, 64) >= TARGET)) launch_tile<64, 64, 2, 2>(q, g, batch);
         else if (maxM > 16 && wgs(32, 64) >= TARGET) launch_tile<32, 64, 1, 4>(q, g, batch);
         else if (maxM > 16 && maxM <= 32) launch_tile<32, 64, 1, 4>(q, g, batch);
         else launch_tile<16, 64, 1, 4>(q, g, batch);

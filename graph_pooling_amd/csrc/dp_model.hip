@@ -550,6 +550,7 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
         }
         return;
     }
+    bool part_ready = false;       // layer l's BatchNorm-backward partials were written by layer l + 1's dX GEMM
     for (int l = li.L - 1; l >= 0; --l) {
         const int ct = li.ctot[l];
         const bool last = l == li.L - 1;
@@ -576,9 +577,10 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
         const bool has_bn = !last && bn;
         const float* part2 = part;
         if (has_bn) {
-            bn_bwd_partials(q, dx, xhat, g, part, (long)B * n);
+            if (!part_ready) bn_bwd_partials(q, dx, xhat, g, part, (long)B * n);
             part2 = bn_exchange(q, c, part, part_all, (size_t)B * n * li.G * 2);
         }
+        part_ready = false;
         // bias gradients: column sums of dU go straight into each graph's (zeroed) slab row with float atomics
         GroupPtrs dbias{};
         dbias.p[0] = li.e->b_off[l] >= 0 ? slabs + li.e->b_off[l] : nullptr;
@@ -618,6 +620,14 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
         {
             GemmDesc d[4];
             int nd = 0;
+            // The dX products of this layer complete the gradient of layer l - 1's output: when that layer has a
+            // BatchNorm its backward partials (row sums of dx and dx * xhat) ride in the epilogue of those products
+            // instead of a k_bn_bwd_partials launch (narrow layers, no dropout mask in the way).
+            bool hook = l >= 1 && bn && !knobs().no_rowpart_hook;
+            for (int gi = 0; gi < li.G && hook; ++gi) {
+                const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
+                hook = gemm_rowpart_ok(st->dims[l]) && !drop_mask(li, io, gi, l);
+            }
             float* masked_dst[2] = {nullptr, nullptr};
             const float* masked_m[2] = {nullptr, nullptr};
             int masked_ld[2] = {0, 0}, masked_w[2] = {0, 0};
@@ -661,12 +671,24 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
                     d[nd++] = GemmDesc{Gj + g.c0[gi], PW(params, st->w_off[l]), dxm[gi], nullptr, n, din, dout, ct, dout,
                                        din, (long)n * ct, 0, (long)n * din, false, true, 1.f, 0.f, 0, 0, 0, nullptr, 0, 0,
                                        0, 1};
+                } else if (dxin && hook) {
+                    // whole K in one workgroup, plain read-modify-write of the dZ slice, partials of the final values
+                    GemmDesc h{Gj + g.c0[gi], PW(params, st->w_off[l]), dxin, nullptr, n, din, dout, ct, dout,
+                               lddx, (long)n * ct, 0, (long)n * lddx, false, true, 1.f, 1.f, 0, 0, 0};
+                    h.nosplit = 1;
+                    h.rp_xhat = gi == 0 ? lv.Ze + li.coff_e[l - 1] : lv.Za + li.coff_a[l - 1];
+                    h.rp_ldx = gi == 0 ? li.D : li.Da;
+                    h.rp_part = part;
+                    h.rp_G = li.G;
+                    h.rp_g = gi;
+                    d[nd++] = h;
                 } else if (dxin)   // accumulates into dZ: atomic so split-K ranges (only > 1 for wide layers) cannot race
                     d[nd++] = GemmDesc{Gj + g.c0[gi], PW(params, st->w_off[l]), dxin, nullptr, n, din, dout, ct, dout,
                                        lddx, (long)n * ct, 0, (long)n * lddx, false, true, 1.f, 1.f, 0, 0,
                                        ks_level > 1 ? 1 : 0};
             }
             bgemm_group(q, d, nd, B, ks_level);
+            part_ready = hook;
             for (int gi = 0; gi < li.G; ++gi)
                 if (masked_dst[gi])
                     mask_axpy(q, masked_dst[gi], masked_ld[gi], dxm[gi], masked_m[gi], (long)B * n, masked_w[gi]);
