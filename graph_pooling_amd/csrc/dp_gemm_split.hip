@@ -38,8 +38,9 @@ typedef unsigned short sg_u16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SG_BM = 128, SG_BN = 128, SG_KT = 32;
 constexpr int SG_LDK = 40;                          // bf16 elements per LDS row
-constexpr int SG_PLANE = SG_BM * SG_LDK;            // elements of one plane of one operand (BM == BN)
-constexpr int SG_LDS_BYTES = 2 * 3 * SG_PLANE * 2;  // A and B, three planes, 2 bytes
+constexpr int SG_PLANE = SG_BM * SG_LDK;            // elements of one plane of a 128-row operand tile
+constexpr int sg_lds_bytes(int bn) { return 3 * (SG_BM + bn) * SG_LDK * 2; }   // A and B tiles, three planes, 2 bytes
+constexpr int SG_LDS_BYTES = sg_lds_bytes(SG_BN);
 
 struct SplitGemmArgs {
     const float* A;
@@ -72,10 +73,10 @@ struct SgRegs {
 // partial k-slab): a quad that sticks out of the contiguous dimension is read shifted back so that it ENDS at the
 // rim, and sg_fix() — after the loads are in flight — undoes the shift and zeroes what lies outside.
 // NQ = quads per thread and operand slab: 4 with 256 threads, 2 with 512.
-template <bool KC, int NQ>
+// NT = threads of the workgroup (256 or 512); a 128-row tile is NQ = 1024 / NT quads per thread, a 64-row tile half that.
+template <bool KC, int NQ, int NT>
 __device__ __forceinline__ void sg_coords(int i, int r0, int k0, int& c, int& o) {
     const int t = threadIdx.x;
-    constexpr int NT = 1024 / NQ;
     int r, k;
     if (KC) {
         const int slot = t + NT * i;            // (row, k-quad): 8 quads per row
@@ -84,21 +85,24 @@ __device__ __forceinline__ void sg_coords(int i, int r0, int k0, int& c, int& o)
     } else if (NQ == 4) {
         r = r0 + (t >> 3) * 4;                  // one 4 k x 4 row block per thread: k-block t & 7, row block t >> 3
         k = k0 + (t & 7) * 4 + i;
-    } else {
+    } else if (NQ == 2) {
         r = r0 + (t >> 4) * 4;                  // one 2 k x 4 row block per thread: k-pair t & 15, row block t >> 4
         k = k0 + (t & 15) * 2 + i;
+    } else {
+        r = r0 + (t >> 5) * 4;                  // one 1 k x 4 row block per thread: k t & 31, row block t >> 5
+        k = k0 + (t & 31);
     }
     c = KC ? k : r;                             // contiguous coordinate of the quad's first element
     o = KC ? r : k;                             // the other coordinate
 }
-template <bool KC, bool EDGE, int NQ>
+template <bool KC, bool EDGE, int NQ, int NT>
 __device__ __forceinline__ void sg_load(const float* __restrict__ p, int ld, int r0, int k0, int rmax, int kmax,
                                         SgRegs<NQ>& s) {
     const int cmax = KC ? kmax : rmax, omax = KC ? rmax : kmax;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         int c, o;
-        sg_coords<KC, NQ>(i, r0, k0, c, o);
+        sg_coords<KC, NQ, NT>(i, r0, k0, c, o);
         if (EDGE) {
             c = min(c, cmax - 4);
             o = min(o, omax - 1);
@@ -106,13 +110,13 @@ __device__ __forceinline__ void sg_load(const float* __restrict__ p, int ld, int
         s.q[i] = *reinterpret_cast<const sg_f32x4_u*>(p + (long)o * ld + c);
     }
 }
-template <bool KC, int NQ>
+template <bool KC, int NQ, int NT>
 __device__ __forceinline__ void sg_fix(int r0, int k0, int rmax, int kmax, SgRegs<NQ>& s) {
     const int cmax = KC ? kmax : rmax, omax = KC ? rmax : kmax;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         int c, o;
-        sg_coords<KC, NQ>(i, r0, k0, c, o);
+        sg_coords<KC, NQ, NT>(i, r0, k0, c, o);
         const int shift = c - min(c, cmax - 4);          // 0 inside; 1..3 on the rim; >= 4 wholly outside
         const bool dead = o >= omax;
         const sg_f32x4 v = s.q[i];
@@ -159,10 +163,9 @@ __device__ __forceinline__ void sg_split_pair(float a, float b, unsigned& h, uns
 typedef unsigned sg_u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- registers -> LDS planes [plane][row][k]
-template <bool KC, int NQ>
+template <bool KC, int NQ, int NT, int PLANE>
 __device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const SgRegs<NQ>& s) {
     const int t = threadIdx.x;
-    constexpr int NT = 1024 / NQ;
     if (KC) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
@@ -173,8 +176,8 @@ __device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const
             sg_split_pair(s.q[i][2], s.q[i][3], h1, m1, l1);
             unsigned short* d = img + r * SG_LDK + k;
             *reinterpret_cast<sg_u32x2*>(d) = (sg_u32x2){h0, h1};
-            *reinterpret_cast<sg_u32x2*>(d + SG_PLANE) = (sg_u32x2){m0, m1};
-            *reinterpret_cast<sg_u32x2*>(d + 2 * SG_PLANE) = (sg_u32x2){l0, l1};
+            *reinterpret_cast<sg_u32x2*>(d + PLANE) = (sg_u32x2){m0, m1};
+            *reinterpret_cast<sg_u32x2*>(d + 2 * PLANE) = (sg_u32x2){l0, l1};
         }
     } else if (NQ == 4) {
         // q[i][j] = element (row rb*4 + j, k kb*4 + i): write row j's four k values as one quad
@@ -186,9 +189,24 @@ __device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const
             sg_split_pair(s.q[2][j], s.q[3][j], h1, m1, l1);
             unsigned short* d = img + (r + j) * SG_LDK + k;
             *reinterpret_cast<sg_u32x2*>(d) = (sg_u32x2){h0, h1};
-            *reinterpret_cast<sg_u32x2*>(d + SG_PLANE) = (sg_u32x2){m0, m1};
-            *reinterpret_cast<sg_u32x2*>(d + 2 * SG_PLANE) = (sg_u32x2){l0, l1};
+            *reinterpret_cast<sg_u32x2*>(d + PLANE) = (sg_u32x2){m0, m1};
+            *reinterpret_cast<sg_u32x2*>(d + 2 * PLANE) = (sg_u32x2){l0, l1};
         }
+    } else if (NQ == 1) {
+        // q[0][j] = element (row rb*4 + j, k): one bf16 per plane and row (the 64-row B tile of the 8-wave form)
+        const int r = (t >> 5) * 4, k = t & 31;
+        unsigned h0, m0, l0, h1, m1, l1;
+        sg_split_pair(s.q[0][0], s.q[0][1], h0, m0, l0);
+        sg_split_pair(s.q[0][2], s.q[0][3], h1, m1, l1);
+        unsigned short* d = img + r * SG_LDK + k;
+        d[0] = (unsigned short)h0;            d[SG_LDK] = (unsigned short)(h0 >> 16);
+        d[2 * SG_LDK] = (unsigned short)h1;   d[3 * SG_LDK] = (unsigned short)(h1 >> 16);
+        d += PLANE;
+        d[0] = (unsigned short)m0;            d[SG_LDK] = (unsigned short)(m0 >> 16);
+        d[2 * SG_LDK] = (unsigned short)m1;   d[3 * SG_LDK] = (unsigned short)(m1 >> 16);
+        d += PLANE;
+        d[0] = (unsigned short)l0;            d[SG_LDK] = (unsigned short)(l0 >> 16);
+        d[2 * SG_LDK] = (unsigned short)l1;   d[3 * SG_LDK] = (unsigned short)(l1 >> 16);
     } else {
         // q[i][j] = element (row rb*4 + j, k kb*2 + i): row j's two k values as one 4-byte store
         const int r = (t >> 4) * 4, k = (t & 15) * 2;
@@ -198,8 +216,8 @@ __device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const
             sg_split_pair(s.q[0][j], s.q[NQ - 1][j], h, m, l);
             unsigned short* d = img + (r + j) * SG_LDK + k;
             *reinterpret_cast<unsigned*>(d) = h;
-            *reinterpret_cast<unsigned*>(d + SG_PLANE) = m;
-            *reinterpret_cast<unsigned*>(d + 2 * SG_PLANE) = l;
+            *reinterpret_cast<unsigned*>(d + PLANE) = m;
+            *reinterpret_cast<unsigned*>(d + 2 * PLANE) = l;
         }
     }
 }
@@ -209,19 +227,26 @@ __device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const
 
 // NW waves per workgroup: 4 (2 x 2, 64 x 64 per wave) or 8 (4 x 2, 32 x 64 per wave: half the split work per thread and
 // four waves per SIMD to hide its dependent convert / subtract chains).
-template <bool TA, bool TB, int NW>
+// BN = 128, or 64 for products with a narrow output (N <= 64: the pooling products X' = S^T Z, dZ += S dX' at 60
+// columns): the waves then stack along M only (NW x 1, 128 / NW rows x 64 columns each).
+template <bool TA, bool TB, int NW, int BN>
 __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsigned short* lds) {
-    constexpr int MI = 16 / NW;                 // 16-row MFMA tiles per wave: 4 or 2
-    constexpr int NQ = 1024 / (NW * 64);        // quads per thread and operand slab
+    constexpr int NT = NW * 64;
+    constexpr int WC = BN / 64;                 // wave columns: 2 or 1
+    constexpr int WR = NW / WC;                 // wave rows
+    constexpr int MI = 8 / WR;                  // 16-row MFMA tiles per wave
+    constexpr int NQ = 1024 / NT;               // quads per thread and 128-row operand slab
+    constexpr int NQB = NQ * BN / 128;          // ... and B slab
+    constexpr int PLANE_B = BN * SG_LDK;
     const int b = blockIdx.y;
-    const int m0 = (tile / a.tilesN) * SG_BM, n0 = (tile % a.tilesN) * SG_BN;
+    const int m0 = (tile / a.tilesN) * SG_BM, n0 = (tile % a.tilesN) * BN;
     const float* A = a.A + (long)b * a.sA;
     const float* B = a.B + (long)b * a.sB;
     float* C = a.C + (long)b * a.sC;
     unsigned short* As = lds;
     unsigned short* Bs = lds + 3 * SG_PLANE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;     // NW / 2 wave rows of 16 * MI rows, 2 wave columns of 64
+    const int wr = wave / WC, wc = wave % WC;    // WR wave rows of 16 * MI rows, WC wave columns of 64
     const int l15 = lane & 15, kq = lane >> 4;
 
     sg_f32x4 acc[MI][4];
@@ -239,22 +264,23 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
     // vector instructions per thread and slab in dependent convert / shift / subtract chains, two waves per SIMD to
     // hide them) costs as much as everything else together.  Eight waves per workgroup (half the elements per thread,
     // four waves per SIMD) is the next form to try.
-    SgRegs<NQ> ra0, rb0;
+    SgRegs<NQ> ra0;
+    SgRegs<NQB> rb0;
     const int nk = (a.K + SG_KT - 1) / SG_KT;
-    const bool rimA = m0 + SG_BM > a.M, rimB = n0 + SG_BN > a.N;      // wave-uniform
-    auto fetch = [&](int kt, SgRegs<NQ>& ra, SgRegs<NQ>& rb) {
+    const bool rimA = m0 + SG_BM > a.M, rimB = n0 + BN > a.N;      // wave-uniform
+    auto fetch = [&](int kt, SgRegs<NQ>& ra, SgRegs<NQB>& rb) {
         const int k0 = kt * SG_KT;
         const bool tail = k0 + SG_KT > a.K;
-        if (rimA || tail) sg_load<!TA, true, NQ>(A, a.lda, m0, k0, a.M, a.K, ra);
-        else sg_load<!TA, false, NQ>(A, a.lda, m0, k0, a.M, a.K, ra);
-        if (rimB || tail) sg_load<TB, true, NQ>(B, a.ldb, n0, k0, a.N, a.K, rb);
-        else sg_load<TB, false, NQ>(B, a.ldb, n0, k0, a.N, a.K, rb);
+        if (rimA || tail) sg_load<!TA, true, NQ, NT>(A, a.lda, m0, k0, a.M, a.K, ra);
+        else sg_load<!TA, false, NQ, NT>(A, a.lda, m0, k0, a.M, a.K, ra);
+        if (rimB || tail) sg_load<TB, true, NQB, NT>(B, a.ldb, n0, k0, a.N, a.K, rb);
+        else sg_load<TB, false, NQB, NT>(B, a.ldb, n0, k0, a.N, a.K, rb);
     };
-    auto fix = [&](int kt, SgRegs<NQ>& ra, SgRegs<NQ>& rb) {        // after the wait the LDS write needs anyway
+    auto fix = [&](int kt, SgRegs<NQ>& ra, SgRegs<NQB>& rb) {        // after the wait the LDS write needs anyway
         const int k0 = kt * SG_KT;
         const bool tail = k0 + SG_KT > a.K;
-        if (rimA || tail) sg_fix<!TA, NQ>(m0, k0, a.M, a.K, ra);
-        if (rimB || tail) sg_fix<TB, NQ>(n0, k0, a.N, a.K, rb);
+        if (rimA || tail) sg_fix<!TA, NQ, NT>(m0, k0, a.M, a.K, ra);
+        if (rimB || tail) sg_fix<TB, NQB, NT>(n0, k0, a.N, a.K, rb);
     };
     auto multiply = [&]() {
         // ---- 64 x 64 x 32 per wave.  The six plane products of a column tile run product by product over the four
@@ -271,7 +297,7 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
             sg_s16x8 bf[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                bf[p] = *reinterpret_cast<const sg_s16x8*>(Bs + p * SG_PLANE + (wc * 64 + j * 16 + l15) * SG_LDK + kq * 8);
+                bf[p] = *reinterpret_cast<const sg_s16x8*>(Bs + p * PLANE_B + (wc * 64 + j * 16 + l15) * SG_LDK + kq * 8);
 #pragma unroll
             for (int i = 0; i < MI; ++i) SG_MFMA(af[1][i], bf[1], acc[i][j]);
 #pragma unroll
@@ -290,8 +316,8 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
     for (int kt = 0; kt < nk; ++kt) {
         if (kt > 0) __syncthreads();                       // the previous slab's readers are done
         fix(kt, ra0, rb0);
-        sg_store<!TA, NQ>(As, ra0);
-        sg_store<TB, NQ>(Bs, rb0);
+        sg_store<!TA, NQ, NT, SG_PLANE>(As, ra0);
+        sg_store<TB, NQB, NT, PLANE_B>(Bs, rb0);
         __syncthreads();
         if (kt + 1 < nk) fetch(kt + 1, ra0, rb0);
         multiply();
@@ -343,16 +369,16 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
         }
 }
 
-template <int NW>
+template <int NW, int BN = SG_BN>
 __global__ __launch_bounds__(NW * 64) void k_gemm_split_bf16(SplitGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short sg_lds[];
     const int tile = blockIdx.x;
     if (a.tA) {
-        if (a.tB) sg_body<true, true, NW>(a, tile, sg_lds);
-        else sg_body<true, false, NW>(a, tile, sg_lds);
+        if (a.tB) sg_body<true, true, NW, BN>(a, tile, sg_lds);
+        else sg_body<true, false, NW, BN>(a, tile, sg_lds);
     } else {
-        if (a.tB) sg_body<false, true, NW>(a, tile, sg_lds);
-        else sg_body<false, false, NW>(a, tile, sg_lds);
+        if (a.tB) sg_body<false, true, NW, BN>(a, tile, sg_lds);
+        else sg_body<false, false, NW, BN>(a, tile, sg_lds);
     }
 }
 
@@ -366,8 +392,11 @@ bool gemm_split_usable(const GemmDesc& d, int batch, int ksplit) {
     if ((d.bias || d.act) && d.beta != 0.f) return false;
     if (d.split_out && d.beta != 0.f) return false;
     if (d.alpha != 1.f || !(d.beta == 0.f || d.beta == 1.f)) return false;
-    if (d.M < 96 || d.N < 96 || d.K < 48) return false;       // (the rim loads also need every extent >= 4)
-    const long tiles = (long)((d.M + SG_BM - 1) / SG_BM) * ((d.N + SG_BN - 1) / SG_BN) * batch;
+    // N in [48, 64]: the 128 x 64 tile (8-wave form only)
+    const bool narrow = d.N >= 48 && d.N <= 64 && !knobs().split_gemm_w4 && !d.split_out;
+    if (d.M < 96 || (d.N < 96 && !narrow) || d.K < 48) return false;       // (the rim loads also need every extent >= 4)
+    const int bn = narrow ? 64 : SG_BN;
+    const long tiles = (long)((d.M + SG_BM - 1) / SG_BM) * ((d.N + bn - 1) / bn) * batch;
     return tiles >= 256;
 }
 
@@ -378,6 +407,18 @@ void gemm_split_bf16(Seq& q, const GemmDesc& d, int batch) {
         return;
     }
     const bool w8 = !knobs().split_gemm_w4;
+    if (w8 && d.N <= 64) {
+        static DynLdsOnce attr64;
+        ensure_dyn_lds(q, attr64, reinterpret_cast<const void*>(&k_gemm_split_bf16<8, 64>), sg_lds_bytes(64),
+                       "k_gemm_split_bf16<8,64>");
+        if (!q.ok()) return;
+        SplitGemmArgs a{d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.sA, d.sB, d.sC, d.tA ? 1 : 0, d.tB ? 1 : 0,
+                        d.beta, 1, d.split_out, d.split_ct, d.split_k8, d.split_c0, d.bias, d.act};
+        const int tiles = (d.M + SG_BM - 1) / SG_BM;
+        hipLaunchKernelGGL((k_gemm_split_bf16<8, 64>), dim3(tiles, batch), dim3(512), sg_lds_bytes(64), q.stream, a);
+        q.check_launch("gemm_split_bf16");
+        return;
+    }
     static DynLdsOnce attr4, attr8;
     if (w8) ensure_dyn_lds(q, attr8, reinterpret_cast<const void*>(&k_gemm_split_bf16<8>), SG_LDS_BYTES, "k_gemm_split_bf16<8>");
     else ensure_dyn_lds(q, attr4, reinterpret_cast<const void*>(&k_gemm_split_bf16<4>), SG_LDS_BYTES, "k_gemm_split_bf16<4>");

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_bn_transform(BnTransformArgs t) {
 }
 bool bn_transform_supported(RowGroups gin, RowGroups gout, int B) {
     const int G = gin.G;
-    if (B > 32) return false;                 // (bigger batches finalise the statistics in a launch of their own)
+    (void)B;                                  // (batches above 32 graphs: k_bn_finalize runs in front, bn_transform_fwd)
     size_t wfl = 0;
     for (int g = 0; g < G; ++g) {
         if (gin.w[g] > 64 || gout.w[g] > 128) return false;
@@ -511,6 +511,11 @@ void bn_transform_fwd(Seq& q, const float* Y, int ldy, const float* part, float*
     t.vs = vs;
     const int G = gin.G;
     const int cin = gin.c0[G - 1] + gin.w[G - 1], cout = gout.c0[G - 1] + gout.w[G - 1];
+    if (part && B > 32) {     // big batches: combine the B row partials of a node once, not in each of its B rows
+        hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)(((long)n * G + 15) / 16)), dim3(256), 0, q.stream, t.bn);
+        q.check_launch("bn_finalize");
+        t.bn.stats_ready = 1;
+    }
     t.vs_ct = (cout + 15) / 16;
     t.vs_k8 = ((n + 31) / 32) * 4;
     size_t wfl = 0;

@@ -62,7 +62,10 @@ def test_bgemm_shapes(lib, tA, tB, M, N, K):
 
 @pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K,beta", [(256, 256, 1024, 0.0), (1024, 256, 256, 1.0), (300, 296, 90, 0.0),
-                                        (129, 97, 65, 1.0), (7, 5, 3, 0.0), (128, 128, 32, 0.0)])
+                                        (129, 97, 65, 1.0), (7, 5, 3, 0.0), (128, 128, 32, 0.0),
+                                        # N <= 64: the 128 x 64 tile (the pooling products at 60 columns)
+                                        (256, 60, 1024, 0.0), (1024, 60, 256, 1.0), (130, 64, 70, 0.0),
+                                        (200, 33, 50, 1.0)])
 def test_bgemm_split_bf16_is_fp32_grade(lib, tA, tB, M, N, K, beta):
     """dp_bgemm_split_bf16: both fp32 operands split into three bf16 planes, six plane products on the bf16 MFMA.
     Wide-dynamic-range operands (values over 6 decades, mixed signs); against an fp64 product the error must be within a
@@ -91,6 +94,18 @@ def test_bgemm_split_bf16_is_fp32_grade(lib, tA, tB, M, N, K, beta):
 def test_bgemm_split_bf16_identity_asymmetric(lib):
     # A = I against an asymmetric B: catches a transposed C write or a k permutation that differs between the operands
     M = N = K = 160
+    Bm = torch.arange(K * N, dtype=torch.float32).reshape(K, N) * 0.25
+    Ad, Bd = dev(torch.eye(M).repeat(2, 1, 1)), dev(Bm)
+    Cd = torch.zeros(2, M, N, device="cuda")
+    _lib.check(lib.dp_bgemm_split_bf16(Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), 2, M, N, K, K, N, N, M * K, 0, M * N,
+                                       0, 0, 0.0, S()))
+    close(Cd, Bm.repeat(2, 1, 1), 0, 0)
+
+
+def test_bgemm_split_bf16_identity_narrow_tile(lib):
+    # the same with a 60-column B: the 128 x 64 tile, one bf16 per LDS store on the row-contiguous operand
+    M = K = 160
+    N = 60
     Bm = torch.arange(K * N, dtype=torch.float32).reshape(K, N) * 0.25
     Ad, Bd = dev(torch.eye(M).repeat(2, 1, 1)), dev(Bm)
     Cd = torch.zeros(2, M, N, device="cuda")

@@ -47,3 +47,5 @@ run("dZa          NN 1024x296x256", 1024, 296, 256, 0, 0)
 run("dWp          TN 256x296x1024", 256, 296, 1024, 1, 0)
 run("dS = Z dX'^T NT 1024x256x60", 1024, 256, 60, 0, 1)
 run("A'=T^T S lvl1 TN 256x256x40?", 256, 256, 40, 0, 1)
+run("dZ += S dX'  NN 1024x60x256", 1024, 60, 256, 0, 0)
+run("X' = S^T Z   TN 256x60x1024", 256, 60, 1024, 1, 0)
