@@ -576,12 +576,20 @@ __device__ __forceinline__ void aggw_epilogue(const AggArgs& a, f32x4 (&acc)[2][
 //     one barrier per step.  No LDS-DMA here on purpose: with a glds in flight hipcc drains vmcnt(0) at every
 //     use of an ordinary load (cdna_hip_programming.md §5), which would serialise the A prefetch.
 // Runs only when the pack flag says A is bf16-exact; the caller queues a predicated fp32 launch behind it.
+#ifndef DP_AGGW_KS
+#define DP_AGGW_KS 2      // (tuning: experimental builds override these two.  KS = 4 — 256-byte instead of 128-byte runs per
+                          // adjacency row and step — with NA = 2 or 4 measured 157-158 us against 154 at the ER shape: the
+                          // pass is not limited by the granularity of its row reads)
+#endif
+#ifndef DP_AGGW_NA
+#define DP_AGGW_NA 4
+#endif
 template <int CT>
 __global__ __launch_bounds__(256) void k_aggregate_wide(AggArgs a) {
-    constexpr int KS = CT <= 8 ? 2 : 1;          // k32 sub-steps per pipeline step
+    constexpr int KS = CT <= 4 ? DP_AGGW_KS : CT <= 8 ? 2 : 1; // k32 sub-steps per pipeline step
     constexpr int NP = 3 * CT * KS;              // 1-KiB pieces of split V per step
     constexpr int PPW = (NP + 3) / 4;            // pieces staged per wave
-    constexpr int NA = CT <= 8 ? 4 : 2;          // A register sets (prefetch distance NA - 1 steps; wide steps are long)
+    constexpr int NA = CT <= 4 ? DP_AGGW_NA : CT <= 8 ? 4 : 2; // A register sets (prefetch distance NA - 1 steps; wide steps are long)
     constexpr int NB = CT <= 8 ? 3 : 6;          // split-V fragments kept in flight from LDS ahead of their MFMAs
     extern __shared__ __attribute__((aligned(16))) float ldsf[];
     if (__builtin_amdgcn_readfirstlane(*a.pk_flag) != 0) return;
@@ -844,7 +852,7 @@ static bool aggw_usable(const PackedAdj* pk, const unsigned short* vs, int B, in
 
 template <int CT>
 static void launch_aggw(Seq& q, const AggArgs& a, int B) {
-    constexpr int KS = CT <= 8 ? 2 : 1;
+    constexpr int KS = CT <= 4 ? DP_AGGW_KS : CT <= 8 ? 2 : 1;
     constexpr size_t lds = (size_t)2 * 3 * CT * KS * 1024;
     static_assert(lds <= 160 * 1024, "wide aggregation LDS");
     static DynLdsOnce attr;
