@@ -41,6 +41,7 @@ const Knobs& knobs() {
         k.no_split_gemm = getenv("DP_NO_SPLIT_GEMM") != nullptr;
         k.split_gemm_w4 = getenv("DP_SPLIT_GEMM_W4") != nullptr;
         k.no_agg_first = getenv("DP_NO_AGG_FIRST") != nullptr;
+        k.no_widen_fusion = getenv("DP_NO_WIDEN_FUSION") != nullptr;
         k.no_rowpart_hook = getenv("DP_NO_ROWPART_HOOK") != nullptr;
         k.no_row_quads = getenv("DP_NO_ROW_QUADS") != nullptr;
     });

@@ -138,6 +138,7 @@ struct Knobs {
     bool split_gemm_w4;    // DP_SPLIT_GEMM_W4: the 4-wave form of the split GEMM instead of the 8-wave one
     bool no_row_quads;     // DP_NO_ROW_QUADS: wide row kernels with 4-byte lanes (the pre-quad form)
     bool no_rowpart_hook;  // DP_NO_ROWPART_HOOK: BatchNorm-backward partials in a launch of their own
+    bool no_widen_fusion;  // DP_NO_WIDEN_FUSION: widening layers' row-local products on the GEMM kernels
     bool no_agg_first;     // DP_NO_AGG_FIRST: every GraphConv as A (x W), also the layers that widen a lot
 };
 const Knobs& knobs();
@@ -290,6 +291,9 @@ void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, lo
 void axpy(Seq& q, float* y, const float* x, float a, long count);
 void mask_mul(Seq& q, const float* x, int ldx, const float* m, float* out, long rows, int w);
 void mask_axpy(Seq& q, float* dst, int ldd, const float* src, const float* m, long rows, int w);
+bool widen_fwd_supported(RowGroups g, const int din[2]);
+void widen_fwd(Seq& q, const float* Uin, int ldin, const int c0in[2], const int din[2], const float* const W[2],
+               GroupCPtrs bias, RowGroups g, GroupPtrs yout, float* invn, long rows, int normalize);
 void gather_cols(Seq& q, const float* x0, int ld0, int w0, const float* x1, int ld1, int w1, float* out, long rows);
 void scatter_add_cols(Seq& q, const float* src, float* d0, int ld0, int w0, float* d1, int ld1, int w1, long rows);
 void zero_fill(Seq& q, void* p, size_t bytes);   // wide-store zero kernel (byte kernel for odd sizes); never a memset node

@@ -434,6 +434,7 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
             q.fold_zero_n16 = 16;
         }
         const bool agg_first = layer_agg_first(li, l);
+        bool widen_fused = false;
         if (agg_first) {
             // (A [x_e | x_a]) W: gather the two stacks' inputs, ONE narrow pass over A, then the row-local products
             const int cin = layer_cin(li, l), de = li.e->dims[l], da = li.a ? li.a->dims[l] : 0;
@@ -442,14 +443,31 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
                         (long)B * n);
             aggregate(q, io.adj, Pj, cin, Uin, cin, B, n, cin, false, 0.f, pk, vs, false);
             if (add_self) axpy(q, Uin, Pj, 1.f, (long)B * n * cin);
-            GemmDesc d[2];
-            for (int gi = 0; gi < li.G; ++gi) {
-                const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
-                const int c0 = gi == 0 ? 0 : li.e->dims[l + 1], c0in = gi == 0 ? 0 : de;
-                d[gi] = GemmDesc{Uin + c0in, PW(params, st->w_off[l]), Pj + c0, nullptr, n, st->dims[l + 1], st->dims[l],
-                                 cin, st->dims[l + 1], ct, (long)n * cin, 0, (long)n * ct, false, false, 1.f, 0.f, 0};
+            const int dins[2] = {de, da}, c0ins[2] = {0, de};
+            widen_fused = last && widen_fwd_supported(groups_of(li, l), dins);
+            if (!widen_fused) {
+                GemmDesc d[2];
+                for (int gi = 0; gi < li.G; ++gi) {
+                    const dp_stack_cfg* st = gi == 0 ? li.e : li.a;
+                    const int c0 = gi == 0 ? 0 : li.e->dims[l + 1], c0in = gi == 0 ? 0 : de;
+                    d[gi] = GemmDesc{Uin + c0in, PW(params, st->w_off[l]), Pj + c0, nullptr, n, st->dims[l + 1],
+                                     st->dims[l], cin, st->dims[l + 1], ct, (long)n * cin, 0, (long)n * ct, false, false,
+                                     1.f, 0.f, 0};
+                }
+                bgemm_group(q, d, li.G, B);
+            } else {
+                // the row-local products and the GraphConv tail in one row kernel (the last layer has no statistics)
+                const float* Wg[2] = {PW(params, li.e->w_off[l]), li.a ? PW(params, li.a->w_off[l]) : nullptr};
+                GroupCPtrs wb{};
+                wb.p[0] = PW(params, li.e->b_off[l]);
+                wb.p[1] = li.a ? PW(params, li.a->b_off[l]) : nullptr;
+                GroupPtrs wy{};
+                wy.p[0] = lv.Ze + li.coff_e[l];
+                wy.ld[0] = li.D;
+                wy.p[1] = li.a ? lv.Za + li.coff_a[l] : nullptr;
+                wy.ld[1] = li.Da;
+                widen_fwd(q, Uin, cin, c0ins, dins, Wg, wb, groups_of(li, l), wy, lv.layer[l].invn, (long)B * n, 1);
             }
-            bgemm_group(q, d, li.G, B);
         } else if (!transformed) {
             transform(q, c, li, lv, io, params, l, Pj, presplit ? vs : nullptr);
         }
@@ -479,7 +497,9 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
         }
         const int stats_mode = (!last && bn) ? 1 : 0;
         // aggregation + GraphConv tail in one launch when the panel kernel takes the shape
-        if (agg_first) {
+        if (widen_fused) {
+            // (written by widen_fwd above)
+        } else if (agg_first) {
             rownorm_fwd(q, Pj, ct, nullptr, bias, g, yout, lv.layer[l].invn, stats_mode ? part : nullptr, (long)B * n, 1,
                         stats_mode);
         } else if (!aggregate_rownorm_fwd(q, io.adj, Pj, ct, add_self ? Pj : nullptr, bias, g, yout, lv.layer[l].invn,

@@ -223,6 +223,140 @@ void rownorm_fwd(Seq& q, const float* U, int ldu, const float* P, GroupCPtrs bia
     q.check_launch("rownorm_fwd");
 }
 
+// ------------------------------------------------------------------ widening product + GraphConv tail
+// y = l2norm((A x) W + bias) for a layer run in the reference's own order (dp_model.hip layer_agg_first): the
+// aggregated input row (20-40 floats) is all a row needs, so the product rides in the row kernel — the row's inputs
+// sit in two registers per lane and reach every lane of the 16-lane team by DPP row_share, the weights (22 KB at
+// 20 -> 256) are staged once per workgroup in LDS and read as 16-byte quads — and the 276-column pre-activation is
+// never written: 132 us (GEMM, store-bound at 64-byte segments) + 136 us (k_rownorm_fwd) -> one pass at the output's
+// write rate.  Row groups as in k_rownorm_fwd's quad form; din <= 32 per group; no BatchNorm statistics (last layer).
+struct WidenFwdArgs {
+    RownormFwdArgs r;        // bias, output groups, yout, invn, rows, normalize (U, P, part unused)
+    const float* Uin;        // [rows, ldin]: group g's inputs at columns c0in[g] .. c0in[g] + din[g]
+    int ldin;
+    int c0in[2], din[2];
+    const float* W[2];       // [din_g][w_g] row-major
+};
+template <int K>
+__device__ __forceinline__ float team_share(float v) {      // lane K of the 16-lane row, to every lane of the row
+    return dpp_src<0x150 + K, 0xF, true>(0.f, v);
+}
+typedef float f4a __attribute__((ext_vector_type(4)));       // 16-byte aligned: LDS rows of W
+// KMAX = 20 (hidden_dim's default: no padding) or 32: the contraction is unrolled KMAX deep with no branch (a guarded
+// step per k put every LDS read in its own basic block, each with a full wait: 468 us); weight rows din .. KMAX - 1
+// are zero in LDS, and a team's lanes past din hold zeros.
+template <int NQ, int KMAX>
+__global__ __launch_bounds__(256) void k_widen_fwd(WidenFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int G = a.r.g.G;
+    const int wcnt0 = KMAX * a.r.g.w[0], wcnt1 = G == 2 ? KMAX * a.r.g.w[1] : 0;
+    for (int e = threadIdx.x * 4; e < wcnt0 + wcnt1; e += 1024) {          // (both counts are multiples of 4)
+        const int g = e < wcnt0 ? 0 : 1;
+        const int o = g ? e - wcnt0 : e;
+        const bool live = o < a.din[g] * a.r.g.w[g];
+        const f4u t = *reinterpret_cast<const f4u*>(a.W[g] + (live ? o : 0));
+        *reinterpret_cast<f4a*>(wl + e) = live ? t : (f4u){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const int tl = threadIdx.x & 15;
+    const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long nteams = (long)gridDim.x * 16;
+    const long items = a.r.rows * G;
+    for (long it = team; it < items; it += nteams) {
+        const long row = it / G;
+        const int g = (int)(it % G);
+        const int w = a.r.g.w[g], nq = w >> 2, din = a.din[g];
+        const float* uin = a.Uin + row * a.ldin + a.c0in[g];
+        const float* Wg = wl + (g ? wcnt0 : 0);
+        const float* bias = a.r.bias.p[g];
+        float* y = a.r.yout.p[g] + row * a.r.yout.ld[g];
+        float u0 = uin[min(tl, din - 1)], u1 = uin[min(tl + 16, din - 1)];
+        u0 = tl < din ? u0 : 0.f;
+        u1 = tl + 16 < din ? u1 : 0.f;
+        f4a v[NQ];
+        const float* wq[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int qoff = min(tl + 16 * k, nq - 1) * 4;
+            wq[k] = Wg + qoff;
+            const f4u bq = *reinterpret_cast<const f4u*>(bias ? bias + qoff : a.W[g]);   // (a valid address either way)
+            v[k] = bias ? (f4a)bq : (f4a){0.f, 0.f, 0.f, 0.f};
+        }
+#define DP_WIDEN_STEP(KK)                                                                    \
+    if (KK < KMAX) {                                                                         \
+        const float uk = KK < 16 ? team_share<KK & 15>(u0) : team_share<KK & 15>(u1);        \
+        _Pragma("unroll") for (int k = 0; k < NQ; ++k)                                       \
+            v[k] += uk * *reinterpret_cast<const f4a*>(wq[k] + KK * w);                      \
+    }
+        DP_WIDEN_STEP(0) DP_WIDEN_STEP(1) DP_WIDEN_STEP(2) DP_WIDEN_STEP(3) DP_WIDEN_STEP(4) DP_WIDEN_STEP(5)
+        DP_WIDEN_STEP(6) DP_WIDEN_STEP(7) DP_WIDEN_STEP(8) DP_WIDEN_STEP(9) DP_WIDEN_STEP(10) DP_WIDEN_STEP(11)
+        DP_WIDEN_STEP(12) DP_WIDEN_STEP(13) DP_WIDEN_STEP(14) DP_WIDEN_STEP(15) DP_WIDEN_STEP(16) DP_WIDEN_STEP(17)
+        DP_WIDEN_STEP(18) DP_WIDEN_STEP(19) DP_WIDEN_STEP(20) DP_WIDEN_STEP(21) DP_WIDEN_STEP(22) DP_WIDEN_STEP(23)
+        DP_WIDEN_STEP(24) DP_WIDEN_STEP(25) DP_WIDEN_STEP(26) DP_WIDEN_STEP(27) DP_WIDEN_STEP(28) DP_WIDEN_STEP(29)
+        DP_WIDEN_STEP(30) DP_WIDEN_STEP(31)
+#undef DP_WIDEN_STEP
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            if (tl + 16 * k >= nq) v[k] = (f4a){0.f, 0.f, 0.f, 0.f};
+            ss += v[k][0] * v[k][0] + v[k][1] * v[k][1] + v[k][2] * v[k][2] + v[k][3] * v[k][3];
+        }
+        ss = team_sum(ss);
+        const float inv = a.r.normalize ? 1.f / fmaxf(sqrtf(ss), L2_EPS) : 1.f;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+            if (tl + 16 * k < nq) *reinterpret_cast<f4u*>(y + (tl + 16 * k) * 4) = (f4u)(v[k] * inv);
+        if (tl == 0 && a.r.invn) a.r.invn[it] = inv;
+    }
+}
+bool widen_fwd_supported(RowGroups g, const int din[2]) {
+    if (knobs().no_widen_fusion || !row_quads_ok(g)) return false;
+    size_t fl = 0;
+    int maxw = 0;
+    for (int i = 0; i < g.G; ++i) {
+        if (din[i] < 1 || din[i] > 32) return false;
+        fl += (size_t)din[i] * g.w[i];
+        maxw = g.w[i] > maxw ? g.w[i] : maxw;
+    }
+    (void)fl;
+    size_t padded = 0;                               // weight rows are padded to 32 in LDS when some din > 20
+    for (int i = 0; i < g.G; ++i) padded += (size_t)32 * g.w[i];
+    return maxw > 128 && maxw <= 320 && padded * sizeof(float) <= 60 * 1024;
+}
+void widen_fwd(Seq& q, const float* Uin, int ldin, const int c0in[2], const int din[2], const float* const W[2],
+               GroupCPtrs bias, RowGroups g, GroupPtrs yout, float* invn, long rows, int normalize) {
+    if (!q.ok() || rows <= 0) return;
+    WidenFwdArgs a{};
+    a.r = RownormFwdArgs{nullptr, 0, nullptr, bias, g, yout, invn, nullptr, rows, normalize, 0};
+    a.Uin = Uin;
+    a.ldin = ldin;
+    size_t fl = 0;
+    int maxw = 0;
+    for (int i = 0; i < 2; ++i) {
+        a.c0in[i] = c0in[i];
+        a.din[i] = i < g.G ? din[i] : 0;
+        a.W[i] = W[i];
+        if (i < g.G) {
+            fl += (size_t)din[i] * g.w[i];
+            maxw = g.w[i] > maxw ? g.w[i] : maxw;
+        }
+    }
+    (void)fl;
+    int maxd = 0, wsum = 0;
+    for (int i = 0; i < g.G; ++i) {
+        maxd = din[i] > maxd ? din[i] : maxd;
+        wsum += g.w[i];
+    }
+    const dim3 grid(team_grid(rows * g.G));
+    const int kmax = maxd <= 20 ? 20 : 32;
+    const size_t lds = (size_t)kmax * wsum * sizeof(float);
+    if (maxw <= 256 && kmax == 20) hipLaunchKernelGGL((k_widen_fwd<4, 20>), grid, dim3(256), lds, q.stream, a);
+    else if (maxw <= 256) hipLaunchKernelGGL((k_widen_fwd<4, 32>), grid, dim3(256), lds, q.stream, a);
+    else if (kmax == 20) hipLaunchKernelGGL((k_widen_fwd<5, 20>), grid, dim3(256), lds, q.stream, a);
+    else hipLaunchKernelGGL((k_widen_fwd<5, 32>), grid, dim3(256), lds, q.stream, a);
+    q.check_launch("widen_fwd");
+}
+
 // ------------------------------------------------------------------ bn apply fwd
 // apply_bn (encoders.py:1048-1052): per node index n, statistics over (batch, feature), biased variance,
 // eps 1e-5.  Each row team combines the B per-row partials (row mean, row M2) of its node index itself
