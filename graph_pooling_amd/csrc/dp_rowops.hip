@@ -246,6 +246,56 @@ typedef float f4a __attribute__((ext_vector_type(4)));       // 16-byte aligned:
 // step per k put every LDS read in its own basic block, each with a full wait: 468 us); weight rows din .. KMAX - 1
 // are zero in LDS, and a team's lanes past din hold zeros.
 template <int NQ, int KMAX>
+__device__ __forceinline__ void widen_item(const WidenFwdArgs& a, const float* Wg, long row, int g, int tl) {
+    const int G = a.r.g.G;
+    const int w = a.r.g.w[g], nq = w >> 2, din = a.din[g];
+    const float* uin = a.Uin + row * a.ldin + a.c0in[g];
+    const float* bias = a.r.bias.p[g];
+    float* y = a.r.yout.p[g] + row * a.r.yout.ld[g];
+    float u0 = uin[min(tl, din - 1)], u1 = uin[min(tl + 16, din - 1)];
+    u0 = tl < din ? u0 : 0.f;
+    u1 = tl + 16 < din ? u1 : 0.f;
+    f4a v[NQ];
+    const float* wq[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const int qoff = min(tl + 16 * k, nq - 1) * 4;
+        wq[k] = Wg + qoff;
+        const f4u bq = *reinterpret_cast<const f4u*>(bias ? bias + qoff : a.W[g]);   // (a valid address either way)
+        v[k] = bias ? (f4a)bq : (f4a){0.f, 0.f, 0.f, 0.f};
+    }
+#define DP_WIDEN_STEP(KK)                                                                    \
+    if (KK < KMAX) {                                                                         \
+        const float uk = KK < 16 ? team_share<KK & 15>(u0) : team_share<KK & 15>(u1);        \
+        _Pragma("unroll") for (int k = 0; k < NQ; ++k)                                       \
+            v[k] += uk * *reinterpret_cast<const f4a*>(wq[k] + KK * w);                      \
+    }
+    DP_WIDEN_STEP(0) DP_WIDEN_STEP(1) DP_WIDEN_STEP(2) DP_WIDEN_STEP(3) DP_WIDEN_STEP(4) DP_WIDEN_STEP(5)
+    DP_WIDEN_STEP(6) DP_WIDEN_STEP(7) DP_WIDEN_STEP(8) DP_WIDEN_STEP(9) DP_WIDEN_STEP(10) DP_WIDEN_STEP(11)
+    DP_WIDEN_STEP(12) DP_WIDEN_STEP(13) DP_WIDEN_STEP(14) DP_WIDEN_STEP(15) DP_WIDEN_STEP(16) DP_WIDEN_STEP(17)
+    DP_WIDEN_STEP(18) DP_WIDEN_STEP(19) DP_WIDEN_STEP(20) DP_WIDEN_STEP(21) DP_WIDEN_STEP(22) DP_WIDEN_STEP(23)
+    DP_WIDEN_STEP(24) DP_WIDEN_STEP(25) DP_WIDEN_STEP(26) DP_WIDEN_STEP(27) DP_WIDEN_STEP(28) DP_WIDEN_STEP(29)
+    DP_WIDEN_STEP(30) DP_WIDEN_STEP(31)
+#undef DP_WIDEN_STEP
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        if (tl + 16 * k >= nq) v[k] = (f4a){0.f, 0.f, 0.f, 0.f};
+        ss += v[k][0] * v[k][0] + v[k][1] * v[k][1] + v[k][2] * v[k][2] + v[k][3] * v[k][3];
+    }
+    ss = team_sum(ss);
+    const float inv = a.r.normalize ? 1.f / fmaxf(sqrtf(ss), L2_EPS) : 1.f;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+        if (tl + 16 * k < nq) *reinterpret_cast<f4u*>(y + (tl + 16 * k) * 4) = (f4u)(v[k] * inv);
+    if (tl == 0 && a.r.invn) a.r.invn[row * G + g] = inv;
+}
+// KMAX = 20 (hidden_dim's default: no padding) or 32: the contraction is unrolled KMAX deep with no branch (a guarded
+// step per k put every LDS read in its own basic block, each with a full wait: 468 us); weight rows din .. KMAX - 1
+// are zero in LDS, and a team's lanes past din hold zeros.  Items run group by group (all rows of group 0, then all of
+// group 1), so the teams of a wave share a group and a group of at most 64 columns takes the one-quad form: its
+// 20-column rows cost a quarter of the LDS reads of the 256-column ones instead of the same.
+template <int NQ, int KMAX>
 __global__ __launch_bounds__(256) void k_widen_fwd(WidenFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     const int G = a.r.g.G;
@@ -263,50 +313,11 @@ __global__ __launch_bounds__(256) void k_widen_fwd(WidenFwdArgs a) {
     const long nteams = (long)gridDim.x * 16;
     const long items = a.r.rows * G;
     for (long it = team; it < items; it += nteams) {
-        const long row = it / G;
-        const int g = (int)(it % G);
-        const int w = a.r.g.w[g], nq = w >> 2, din = a.din[g];
-        const float* uin = a.Uin + row * a.ldin + a.c0in[g];
+        const int g = it >= a.r.rows ? 1 : 0;
+        const long row = g ? it - a.r.rows : it;
         const float* Wg = wl + (g ? wcnt0 : 0);
-        const float* bias = a.r.bias.p[g];
-        float* y = a.r.yout.p[g] + row * a.r.yout.ld[g];
-        float u0 = uin[min(tl, din - 1)], u1 = uin[min(tl + 16, din - 1)];
-        u0 = tl < din ? u0 : 0.f;
-        u1 = tl + 16 < din ? u1 : 0.f;
-        f4a v[NQ];
-        const float* wq[NQ];
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            const int qoff = min(tl + 16 * k, nq - 1) * 4;
-            wq[k] = Wg + qoff;
-            const f4u bq = *reinterpret_cast<const f4u*>(bias ? bias + qoff : a.W[g]);   // (a valid address either way)
-            v[k] = bias ? (f4a)bq : (f4a){0.f, 0.f, 0.f, 0.f};
-        }
-#define DP_WIDEN_STEP(KK)                                                                    \
-    if (KK < KMAX) {                                                                         \
-        const float uk = KK < 16 ? team_share<KK & 15>(u0) : team_share<KK & 15>(u1);        \
-        _Pragma("unroll") for (int k = 0; k < NQ; ++k)                                       \
-            v[k] += uk * *reinterpret_cast<const f4a*>(wq[k] + KK * w);                      \
-    }
-        DP_WIDEN_STEP(0) DP_WIDEN_STEP(1) DP_WIDEN_STEP(2) DP_WIDEN_STEP(3) DP_WIDEN_STEP(4) DP_WIDEN_STEP(5)
-        DP_WIDEN_STEP(6) DP_WIDEN_STEP(7) DP_WIDEN_STEP(8) DP_WIDEN_STEP(9) DP_WIDEN_STEP(10) DP_WIDEN_STEP(11)
-        DP_WIDEN_STEP(12) DP_WIDEN_STEP(13) DP_WIDEN_STEP(14) DP_WIDEN_STEP(15) DP_WIDEN_STEP(16) DP_WIDEN_STEP(17)
-        DP_WIDEN_STEP(18) DP_WIDEN_STEP(19) DP_WIDEN_STEP(20) DP_WIDEN_STEP(21) DP_WIDEN_STEP(22) DP_WIDEN_STEP(23)
-        DP_WIDEN_STEP(24) DP_WIDEN_STEP(25) DP_WIDEN_STEP(26) DP_WIDEN_STEP(27) DP_WIDEN_STEP(28) DP_WIDEN_STEP(29)
-        DP_WIDEN_STEP(30) DP_WIDEN_STEP(31)
-#undef DP_WIDEN_STEP
-        float ss = 0.f;
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            if (tl + 16 * k >= nq) v[k] = (f4a){0.f, 0.f, 0.f, 0.f};
-            ss += v[k][0] * v[k][0] + v[k][1] * v[k][1] + v[k][2] * v[k][2] + v[k][3] * v[k][3];
-        }
-        ss = team_sum(ss);
-        const float inv = a.r.normalize ? 1.f / fmaxf(sqrtf(ss), L2_EPS) : 1.f;
-#pragma unroll
-        for (int k = 0; k < NQ; ++k)
-            if (tl + 16 * k < nq) *reinterpret_cast<f4u*>(y + (tl + 16 * k) * 4) = (f4u)(v[k] * inv);
-        if (tl == 0 && a.r.invn) a.r.invn[it] = inv;
+        if (a.r.g.w[g] <= 64) widen_item<1, KMAX>(a, Wg, row, g, tl);
+        else widen_item<NQ, KMAX>(a, Wg, row, g, tl);
     }
 }
 bool widen_fwd_supported(RowGroups g, const int din[2]) {
