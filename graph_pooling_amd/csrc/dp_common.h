@@ -291,6 +291,11 @@ void reduce_slabs(Seq& q, const float* slabs, long stride, int B, float* out, lo
 void axpy(Seq& q, float* y, const float* x, float a, long count);
 void mask_mul(Seq& q, const float* x, int ldx, const float* m, float* out, long rows, int w);
 void mask_axpy(Seq& q, float* dst, int ldd, const float* src, const float* m, long rows, int w);
+bool rownorm_bwd_mv_supported(RowGroups g, const int din[2], int n);
+void rownorm_bwd_mv(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const float* invn, const float* stats,
+                    const float* part2, RowGroups g, float* dU, int ldu, const GroupPtrs* dbias, int B, int n,
+                    int has_relu, int has_bn, int normalize, int Bs, const float* const W[2], const int din[2],
+                    const int c0in[2], float* dUin, int lddu);
 bool widen_fwd_supported(RowGroups g, const int din[2]);
 void widen_fwd(Seq& q, const float* Uin, int ldin, const int c0in[2], const int din[2], const float* const W[2],
                GroupCPtrs bias, RowGroups g, GroupPtrs yout, float* invn, long rows, int normalize);

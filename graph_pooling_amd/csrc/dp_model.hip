@@ -608,8 +608,19 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
         dbias.ld[0] = dbias.ld[1] = (int)gstride;
         const bool agg_first = layer_agg_first(li, l) && !gr.dAdj;
         const bool presplit = !agg_first && pk && vs && aggregate_packed_usable(io.adj, n, ct);
-        rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, part2, g, dUj, ct, &dbias, B, n, !last, has_bn,
-                    1, presplit ? vs : nullptr, B * W);
+        bool mv_fused = false;       // d(A x) = dV W^T already written by the row kernel
+        if (agg_first) {
+            const int dins[2] = {li.e->dims[l], li.a ? li.a->dims[l] : 0}, c0ins[2] = {0, li.e->dims[l]};
+            mv_fused = rownorm_bwd_mv_supported(g, dins, n);
+            if (mv_fused) {
+                const float* Wg[2] = {PW(params, li.e->w_off[l]), li.a ? PW(params, li.a->w_off[l]) : nullptr};
+                rownorm_bwd_mv(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, part2, g, dUj, ct, &dbias, B, n,
+                               !last, has_bn, 1, B * W, Wg, dins, c0ins, Gj, layer_cin(li, l));
+            }
+        }
+        if (!mv_fused)
+            rownorm_bwd(q, dx, xhat, y, lv.layer[l].invn, lv.layer[l].stats, part2, g, dUj, ct, &dbias, B, n, !last,
+                        has_bn, 1, presplit ? vs : nullptr, B * W);
         if (agg_first) {
             // y = (A x) W: dW = (A x)^T dV with the saved A x;  d(A x) = dV W^T (row-local);  dx += A^T d(A x), one
             // narrow pass over A
@@ -622,9 +633,10 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
                 const int din = st->dims[l], dout = st->dims[l + 1], c0in = gi == 0 ? 0 : de;
                 d[nd++] = GemmDesc{Uin + c0in, dUj + g.c0[gi], slabs + st->w_off[l], nullptr, din, dout, n, cin, ct, dout,
                                    (long)n * cin, (long)n * ct, gstride, true, false, 1.f, 0.f, 0, slab_stride, 0};
-                d[nd++] = GemmDesc{dUj + g.c0[gi], PW(params, st->w_off[l]), Gj + c0in, nullptr, n, din, dout, ct, dout,
-                                   cin, (long)n * ct, 0, (long)n * cin, false, true, 1.f, 0.f, 0, 0, 0, nullptr, 0, 0, 0,
-                                   1};
+                if (!mv_fused)
+                    d[nd++] = GemmDesc{dUj + g.c0[gi], PW(params, st->w_off[l]), Gj + c0in, nullptr, n, din, dout, ct,
+                                       dout, cin, (long)n * ct, 0, (long)n * cin, false, true, 1.f, 0.f, 0, 0, 0, nullptr,
+                                       0, 0, 0, 1};
             }
             bgemm_group(q, d, nd, B, ks_level);
             float* dxagg = dUj;                    // dV is consumed: its buffer takes A^T d(A x)

@@ -967,6 +967,150 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(RownormBwdArgs a) {
         }
     }
 }
+// ------------------------------------------------------------------ rownorm bwd + d(A x) = dV W^T
+// The backward twin of k_widen_fwd for layers run as (A x) W: the item computes dV exactly as k_rownorm_bwd's quad
+// form does (and writes it: dW = (A x)^T dV still needs it) and, with the group's weights staged in LDS, also the
+// row-local product d(A x)[j] = sum_c dV[c] W[j][c] — din 16-lane sums per row — so the [n x din] x [din x 256]^T GEMM
+// launch (135 us at the ER shape) goes.  64 rows per workgroup (the weights are staged once per workgroup), items
+// group by group, narrow groups in the one-quad form.
+struct RownormBwdMvArgs {
+    RownormBwdArgs r;
+    const float* W[2];       // [din_g][w_g] row-major
+    int din[2], c0in[2];
+    float* dUin;             // [B * n, lddu]: group g's columns at c0in[g]
+    int lddu;
+};
+template <int NQ>
+__device__ __forceinline__ void rnb_mv_item(const RownormBwdMvArgs& m, const float* Wg, float* mysum, int b, int node,
+                                            int g, int tl) {
+    const RownormBwdArgs& a = m.r;
+    const long row = (long)b * a.n + node;
+    const int w = a.g.w[g], nq = w >> 2;
+    const float* dx = a.dx.p[g] + row * a.dx.ld[g];
+    const float* y = a.y.p[g] + row * a.y.ld[g];
+    const float* xh = a.has_bn ? a.xhat.p[g] + row * a.xhat.ld[g] : dx;
+    f4u dxv[NQ], yv[NQ], xhv[NQ];
+    int qoff[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        qoff[k] = min(tl + 16 * k, nq - 1) * 4;
+        dxv[k] = *reinterpret_cast<const f4u*>(dx + qoff[k]);
+        yv[k] = *reinterpret_cast<const f4u*>(y + qoff[k]);
+        xhv[k] = *reinterpret_cast<const f4u*>(xh + qoff[k]);
+    }
+    const float rstd_l = (a.has_bn ? a.stats : dx)[a.has_bn ? ((long)node * a.g.G + g) * 2 + 1 : 0];
+    const float inv_l = (a.normalize ? a.invn : dx)[a.normalize ? row * a.g.G + g : 0];
+    float s0 = 0.f, s1 = 0.f;
+    {
+        const long pstride = (long)a.n * a.g.G * 2;
+        const float* p = (a.has_bn ? a.part2 : dx) + (a.has_bn ? ((long)node * a.g.G + g) * 2 : 0);
+        const int nb = (a.has_bn && !a.means_ready) ? a.Bs : 0;
+        for (int bb = tl; bb < nb; bb += 16) {
+            s0 += p[bb * pstride];
+            s1 += p[bb * pstride + 1];
+        }
+        if (a.means_ready) {
+            s0 = p[0];
+            s1 = p[1];
+        }
+    }
+    const float cnt = (float)a.Bs * (float)w;
+    const float rstd = a.has_bn ? rstd_l : 1.f;
+    const float m0 = !a.has_bn ? 0.f : a.means_ready ? s0 : team_sum(s0) / cnt;
+    const float m1 = !a.has_bn ? 0.f : a.means_ready ? s1 : team_sum(s1) / cnt;
+    const float inv = a.normalize ? inv_l : 1.f;
+    const bool project = a.normalize && (inv < 1.0f / L2_EPS);
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float d = dxv[k][j];
+            if (a.has_bn) d = rstd * (d - m0 - xhv[k][j] * m1);
+            if (a.has_relu) d = yv[k][j] > 0.f ? d : 0.f;
+            if (tl + 16 * k >= nq) d = 0.f;
+            dxv[k][j] = d;
+            dot += d * yv[k][j];
+        }
+    dot = team_sum(dot);
+    float* du = a.dU + row * a.ldu + a.g.c0[g];
+    f4a dv[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const bool on = tl + 16 * k < nq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = project ? inv * (dxv[k][j] - yv[k][j] * dot) : inv * dxv[k][j];
+            dv[k][j] = on ? t : 0.f;
+        }
+        if (on) {
+            *reinterpret_cast<f4u*>(du + qoff[k]) = (f4u)dv[k];
+            if (a.want_bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mysum[a.g.c0[g] + qoff[k] + j] += dv[k][j];
+            }
+        }
+    }
+    // d(A x)[j] = <dV, W[j, :]>: lane j & 15 keeps sum j
+    const int din = m.din[g];
+    float keep0 = 0.f, keep1 = 0.f;
+#pragma unroll 2
+    for (int j = 0; j < din; ++j) {
+        float p = 0.f;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const f4a w4 = *reinterpret_cast<const f4a*>(Wg + j * w + qoff[k]);
+            p += dv[k][0] * w4[0] + dv[k][1] * w4[1] + dv[k][2] * w4[2] + dv[k][3] * w4[3];
+        }
+        p = team_sum(p);
+        if (tl == (j & 15)) {
+            if (j < 16) keep0 = p;
+            else keep1 = p;
+        }
+    }
+    float* dui = m.dUin + row * m.lddu + m.c0in[g];
+    if (tl < din) dui[tl] = keep0;
+    if (tl + 16 < din) dui[tl + 16] = keep1;
+}
+template <int NQ>
+__global__ __launch_bounds__(256) void k_rownorm_bwd_mv(RownormBwdMvArgs m) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const RownormBwdArgs& a = m.r;
+    const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int G = a.g.G;
+    const int ct = a.g.c0[G - 1] + a.g.w[G - 1];
+    float* colsum = sm;                                       // [16][ct] when bias gradients are wanted
+    float* wl = sm + (a.want_bias ? 16 * ct : 0);             // both groups' weights
+    const int wcnt0 = m.din[0] * a.g.w[0], wcnt1 = G == 2 ? m.din[1] * a.g.w[1] : 0;
+    for (int e = threadIdx.x * 4; e < wcnt0 + wcnt1; e += 1024)
+        *reinterpret_cast<f4a*>(wl + e) =
+            *reinterpret_cast<const f4u*>(e < wcnt0 ? m.W[0] + e : m.W[1] + (e - wcnt0));
+    if (a.want_bias)
+        for (int c = threadIdx.x; c < 16 * ct; c += 256) colsum[c] = 0.f;
+    __syncthreads();
+    float* mysum = colsum + team * ct;
+    const int r0 = chunk * a.rows_per_chunk;
+    const int nrows = min(a.n, r0 + a.rows_per_chunk) - r0;
+    for (int it = team; it < nrows * G; it += 16) {
+        const int g = it >= nrows ? 1 : 0;
+        const int node = r0 + (g ? it - nrows : it);
+        const float* Wg = wl + (g ? wcnt0 : 0);
+        if (a.g.w[g] <= 64) rnb_mv_item<1>(m, Wg, mysum, b, node, g, tl);
+        else rnb_mv_item<NQ>(m, Wg, mysum, b, node, g, tl);
+    }
+    if (!a.want_bias) return;
+    __syncthreads();
+    for (int c = threadIdx.x; c < ct; c += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += colsum[k * ct + c];
+        const int g = (G == 2 && c >= a.g.c0[1]) ? 1 : 0;
+        float* dst = a.dbias.p[g];
+        if (dst) atomicAdd(dst + (long)b * a.dbias.ld[g] + (c - a.g.c0[g]), t);
+    }
+}
+
 // Big batches: the B x ranks partial pairs of a (node, group) are combined ONCE, in place (the result overwrites the
 // pair of graph 0), instead of in every one of the B rows of that node — at B = 256 the on-the-fly combine was 256
 // scattered 8-byte loads per row item: 325 us per launch against ~70 (the forward pass has k_bn_finalize for the same
@@ -1029,6 +1173,60 @@ void rownorm_bwd(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const flo
     else if (maxw <= 256) hipLaunchKernelGGL(k_rownorm_bwd<16>, grid, dim3(256), lds, q.stream, a);
     else hipLaunchKernelGGL(k_rownorm_bwd<0>, grid, dim3(256), lds, q.stream, a);
     q.check_launch("rownorm_bwd");
+}
+
+bool rownorm_bwd_mv_supported(RowGroups g, const int din[2], int n) {
+    if (knobs().no_widen_fusion || !row_quads_ok(g)) return false;
+    const int ct = g.c0[g.G - 1] + g.w[g.G - 1];
+    size_t fl = (size_t)16 * ct;
+    int maxw = 0;
+    for (int i = 0; i < g.G; ++i) {
+        if (din[i] < 1 || din[i] > 32) return false;
+        fl += (size_t)din[i] * g.w[i];
+        maxw = g.w[i] > maxw ? g.w[i] : maxw;
+    }
+    return n >= 1 && maxw > 128 && maxw <= 320 && fl * sizeof(float) <= 60 * 1024;
+}
+// rownorm_bwd (no bf16 split output) + dUin[:, c0in[g] + j] = sum_c dU_g[:, c] W_g[j, c]
+void rownorm_bwd_mv(Seq& q, GroupCPtrs dx, GroupCPtrs xhat, GroupCPtrs y, const float* invn, const float* stats,
+                    const float* part2, RowGroups g, float* dU, int ldu, const GroupPtrs* dbias, int B, int n,
+                    int has_relu, int has_bn, int normalize, int Bs, const float* const W[2], const int din[2],
+                    const int c0in[2], float* dUin, int lddu) {
+    if (!q.ok()) return;
+    if (Bs <= 0) Bs = B;
+    GroupPtrs db{};
+    int want = 0;
+    if (dbias) {
+        db = *dbias;
+        want = (db.p[0] || db.p[1]) ? 1 : 0;
+    }
+    const int ct = g.c0[g.G - 1] + g.w[g.G - 1];
+    RownormBwdMvArgs m{};
+    m.r = RownormBwdArgs{dx, xhat, y, invn, stats, part2, g, dU, ldu, db, want, nullptr, 0, 0,
+                         B, n, 64, has_relu, has_bn, normalize, Bs, 0};
+    if (has_bn && Bs > 32) {
+        hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)(((long)n * g.G + 15) / 16)), dim3(256), 0, q.stream,
+                           const_cast<float*>(part2), Bs, n, g);
+        q.check_launch("bn_bwd_finalize");
+        m.r.means_ready = 1;
+    }
+    size_t fl = want ? (size_t)16 * ct : 0;
+    int maxw = 0;
+    for (int i = 0; i < 2; ++i) {
+        m.W[i] = W[i];
+        m.din[i] = i < g.G ? din[i] : 0;
+        m.c0in[i] = c0in[i];
+        if (i < g.G) {
+            fl += (size_t)din[i] * g.w[i];
+            maxw = g.w[i] > maxw ? g.w[i] : maxw;
+        }
+    }
+    m.dUin = dUin;
+    m.lddu = lddu;
+    const dim3 grid((n + 63) / 64, B);
+    if (maxw <= 256) hipLaunchKernelGGL(k_rownorm_bwd_mv<4>, grid, dim3(256), fl * sizeof(float), q.stream, m);
+    else hipLaunchKernelGGL(k_rownorm_bwd_mv<5>, grid, dim3(256), fl * sizeof(float), q.stream, m);
+    q.check_launch("rownorm_bwd_mv");
 }
 
 // ------------------------------------------------------------------ column sums
