@@ -103,6 +103,12 @@ def test_widening_assign_layer_runs_in_the_reference_association(weighted):
     _run(3, 300, 7, 8, 2, 0.6, weighted=weighted, linkpred=True, p=0.05)
 
 
+def test_widening_layer_with_more_than_twenty_hidden_units():
+    """hidden 28: the row kernels of the widening layer (k_widen_fwd, k_rownorm_bwd_mv) take their 32-deep form (weight
+    rows 28..31 zero in LDS); K = 140 clusters."""
+    _run(2, 280, 6, 28, 2, 0.5, linkpred=True, p=0.05)
+
+
 @pytest.mark.parametrize("concat", [True, False])
 def test_widening_last_layer_of_the_base_encoder(concat):
     """GcnEncoderGraph with embedding_dim 160 from 16 hidden units: conv_last widens 10x and runs as (A x [+ x]) W
