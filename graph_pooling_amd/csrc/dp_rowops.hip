@@ -322,17 +322,14 @@ __global__ __launch_bounds__(256) void k_widen_fwd(WidenFwdArgs a) {
 }
 bool widen_fwd_supported(RowGroups g, const int din[2]) {
     if (knobs().no_widen_fusion || !row_quads_ok(g)) return false;
-    size_t fl = 0;
-    int maxw = 0;
+    int maxw = 0, wsum = 0;
     for (int i = 0; i < g.G; ++i) {
         if (din[i] < 1 || din[i] > 32) return false;
-        fl += (size_t)din[i] * g.w[i];
         maxw = g.w[i] > maxw ? g.w[i] : maxw;
+        wsum += g.w[i];
     }
-    (void)fl;
-    size_t padded = 0;                               // weight rows are padded to 32 in LDS when some din > 20
-    for (int i = 0; i < g.G; ++i) padded += (size_t)32 * g.w[i];
-    return maxw > 128 && maxw <= 320 && padded * sizeof(float) <= 60 * 1024;
+    // (weight rows are padded to 32 in LDS when some din > 20)
+    return maxw > 128 && maxw <= 320 && (size_t)32 * wsum * sizeof(float) <= 60 * 1024;
 }
 void widen_fwd(Seq& q, const float* Uin, int ldin, const int c0in[2], const int din[2], const float* const W[2],
                GroupCPtrs bias, RowGroups g, GroupPtrs yout, float* invn, long rows, int normalize) {
@@ -341,22 +338,16 @@ void widen_fwd(Seq& q, const float* Uin, int ldin, const int c0in[2], const int 
     a.r = RownormFwdArgs{nullptr, 0, nullptr, bias, g, yout, invn, nullptr, rows, normalize, 0};
     a.Uin = Uin;
     a.ldin = ldin;
-    size_t fl = 0;
-    int maxw = 0;
+    int maxw = 0, maxd = 0, wsum = 0;
     for (int i = 0; i < 2; ++i) {
         a.c0in[i] = c0in[i];
         a.din[i] = i < g.G ? din[i] : 0;
         a.W[i] = W[i];
         if (i < g.G) {
-            fl += (size_t)din[i] * g.w[i];
             maxw = g.w[i] > maxw ? g.w[i] : maxw;
+            maxd = din[i] > maxd ? din[i] : maxd;
+            wsum += g.w[i];
         }
-    }
-    (void)fl;
-    int maxd = 0, wsum = 0;
-    for (int i = 0; i < g.G; ++i) {
-        maxd = din[i] > maxd ? din[i] : maxd;
-        wsum += g.w[i];
     }
     const dim3 grid(team_grid(rows * g.G));
     const int kmax = maxd <= 20 ? 20 : 32;
