@@ -1136,6 +1136,12 @@ static void fill_packed(AggArgs& a, const PackedAdj* pk, bool trans, const unsig
     a.vs_k8 = ((n + 31) / 32) * 4;
 }
 
+static bool agg_prefers_split_gemm(const float* A, const float* V, float* U, int B, int n, int C, int ldv, int ldu,
+                                  bool trans, float beta) {
+    if (C < 48) return false;                 // narrow operands: the pass is bound by reading A, the panel kernel's case
+    GemmDesc d{A, V, U, nullptr, n, C, n, n, ldv, ldu, (long)n * n, (long)n * ldv, (long)n * ldu, trans, false, 1.f, beta, 0};
+    return gemm_split_usable(d, B, 1);
+}
 // U[b] (ldu) = op(A[b]) V[b] (+ beta U[b]);  falls back to the generic GEMM for shapes the panel kernel
 // does not take (n not a multiple of 4, C > 128, unaligned A).  With `pk` (a packed copy of A from adj_pack) and a
 // scratch buffer `vs` (split3_elems) the bf16 path is taken when the device flag says A is bf16-exact.
@@ -1145,6 +1151,13 @@ void aggregate(Seq& q, const float* A, const float* V, int ldv, float* U, int ld
     const bool packed = pk && vs && adj_pack_supported(n, C);
     const bool panel = aggregate_supported(A, n, C, trans);
     const bool wide = packed && aggw_usable(pk, vs, B, n, C);
+    if (!packed && agg_prefers_split_gemm(A, V, U, B, n, C, ldv, ldu, trans, beta)) {
+        // a general (pooled, weighted) adjacency at a big batch: both operands are general fp32, which is the split-bf16
+        // GEMM's case — the fp32 panel kernel ran the 84-column level-1 passes of the ER shape at 30 TFLOP/s
+        bgemm(q, A, V, U, nullptr, B, n, C, n, n, ldv, ldu, (long)n * n, (long)n * ldv, (long)n * ldu, trans, false, 1.f,
+              beta, 0);
+        return;
+    }
     AggArgs a{};
     a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = U; a.ldu = ldu; a.beta = beta;
     if (wide) {
@@ -1188,6 +1201,8 @@ bool aggregate_rownorm_fwd(Seq& q, const float* A, const float* V, int ldv, cons
                            int stats_mode, const PackedAdj* pk, unsigned short* vs, bool vs_ready) {
     const int C = g.c0[g.G - 1] + g.w[g.G - 1];
     if (!aggregate_supported(A, n, C, false)) return false;
+    if (!(pk && vs && adj_pack_supported(n, C)) && agg_prefers_split_gemm(A, V, nullptr, B, n, C, ldv, C, false, 0.f))
+        return false;                          // (the caller's two-launch path takes the split GEMM in aggregate())
     if (!q.ok()) return true;
     AggArgs a{};
     a.A = A; a.V = V; a.ldv = ldv; a.n = n; a.C = C; a.U = nullptr;
