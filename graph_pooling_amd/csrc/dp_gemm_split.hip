@@ -394,7 +394,7 @@ bool gemm_split_usable(const GemmDesc& d, int batch, int ksplit) {
     if (d.alpha != 1.f || !(d.beta == 0.f || d.beta == 1.f)) return false;
     // N in [48, 64]: the 128 x 64 tile (8-wave form only)
     const bool narrow = d.N >= 48 && d.N <= 64 && !knobs().split_gemm_w4 && !d.split_out;
-    if (d.M < 96 || (d.N < 80 && !narrow) || d.K < 48) return false;       // (the rim loads also need every extent >= 4)
+    if (d.M < 96 || (d.N < 80 && !narrow) || d.K < 40) return false;       // (the rim loads also need every extent >= 4)
     const int bn = narrow ? 64 : SG_BN;
     const long tiles = (long)((d.M + SG_BM - 1) / SG_BM) * ((d.N + bn - 1) / bn) * batch;
     return tiles >= 256;
