@@ -103,6 +103,17 @@ def test_widening_assign_layer_runs_in_the_reference_association(weighted):
     _run(3, 300, 7, 8, 2, 0.6, weighted=weighted, linkpred=True, p=0.05)
 
 
+@pytest.mark.parametrize("B,N,F_,H,ratio", [
+    (70, 264, 5, 20, 0.5),     # B > 64: no split-K, batch-combined BatchNorm statistics, K = 132 (quad row kernels)
+    (3, 140, 4, 16, 0.95),     # K = 133: not a multiple of 4 -> the 4-byte row kernels and the GEMM products
+    (2, 320, 6, 8, 1.0),       # K = 320 = N: the five-quad forms, 328 joint columns
+])
+def test_widening_layer_shape_sweep(B, N, F_, H, ratio):
+    """More shapes through the (A x) W association and its row kernels, each against the oracle (the fused link
+    loss takes K <= 256 and says so otherwise: off for the 320-cluster case)."""
+    _run(B, N, F_, H, 2, ratio, linkpred=int(N * ratio) <= 256, p=0.04)
+
+
 def test_widening_layer_with_more_than_twenty_hidden_units():
     """hidden 28: the row kernels of the widening layer (k_widen_fwd, k_rownorm_bwd_mv) take their 32-deep form (weight
     rows 28..31 zero in LDS); K = 140 clusters."""
