@@ -924,8 +924,8 @@ bool aggregate_supported(const float* A, int n, int C, bool trans) {
 
 template <bool TRANS, int CT, int RT, int NW>
 static void launch_agg_rt(Seq& q, const AggArgs& a, int B) {
-    // (Sized for the fp32 panel although the bf16 loop needs half of it — 131 KB at n = 1000, one workgroup per CU.
-    // Measured with the bf16-only size, two per CU: DD step 0.3447 vs 0.3449 ms, probe launch 8.1 us both: co-residency
+    // (Sized for the fp32 panel although the bf16 loop needs half of it — 66 KB at n = 500, two workgroups per CU.
+    // Measured with the bf16-only size, four per CU: DD step 0.3447 vs 0.3449 ms, probe launch 8.1 us both: co-residency
     // is not what this launch waits for.)
     const size_t lds = agg_lds_bytes(TRANS, a.n, CT, RT, NW);
     static DynLdsOnce attr;   // per instantiation: allow > 64 KiB of dynamic LDS
