@@ -131,14 +131,21 @@ class _EncoderFn(torch.autograd.Function):
         plan = owner._plan(x.shape[0], x.shape[1], x.device)
         B = plan.cfg.B
         ypred = torch.empty(B, plan.label_dim, device=x.device, dtype=torch.float32)
-        assign = None
-        if plan.cfg.num_pooling > 0:
-            assign = torch.empty(B, plan.cfg.N, plan.cfg.n_nodes[1], device=x.device, dtype=torch.float32)
         save = torch.empty(plan.save_bytes, device=x.device, dtype=torch.uint8) if needs_grad else plan.eval_save()
+        assign = assign_copy = None
+        if plan.cfg.num_pooling > 0:
+            if needs_grad:
+                # a training forward owns a fresh save buffer: assign_tensor is a VIEW of the level-0 S kept there (no
+                # second [B, N, K] write: 268 MB at the ER shape); the view keeps the buffer alive
+                off, cnt = plan.assign_loc
+                assign = save[off:off + 4 * cnt].view(torch.float32).view(B, plan.cfg.N, plan.cfg.n_nodes[1])
+            else:   # the evaluation buffer is reused by the next call: hand out a copy
+                assign = assign_copy = torch.empty(B, plan.cfg.N, plan.cfg.n_nodes[1], device=x.device,
+                                                   dtype=torch.float32)
         stream = _lib.current_stream()
         _lib.check(lib.dp_encoder_forward(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(), adj.data_ptr(),
                                           _lib.ptr(assign_x), _lib.ptr(num_nodes), _lib.ptr(drop), ypred.data_ptr(),
-                                          _lib.ptr(assign), _lib.ptr(labels), save.data_ptr(), plan.save_bytes,
+                                          _lib.ptr(assign_copy), _lib.ptr(labels), save.data_ptr(), plan.save_bytes,
                                           plan.workspace.data_ptr(), plan.ws_bytes,
                                           _lib.MODE_TRAIN if needs_grad else _lib.MODE_EVAL, stream),
                    "dp_encoder_forward")
@@ -213,6 +220,12 @@ class _Plan:
         self._eval_save = None
         self.prezero_owner = None
         self.device = device
+        self.assign_loc = None           # (byte offset, float count) of the level-0 S inside a save buffer
+        if self.cfg.num_pooling > 0:
+            off, cnt = C.c_size_t(0), C.c_size_t(0)
+            _lib.check(lib.dp_encoder_save_locate(C.byref(self.cfg), 0, _lib.SAVE_S, C.byref(off), C.byref(cnt)),
+                       "dp_encoder_save_locate")
+            self.assign_loc = (off.value, cnt.value)
 
     def eval_save(self):
         if self._eval_save is None:
