@@ -300,6 +300,9 @@ bool widen_fwd_supported(RowGroups g, const int din[2]);
 void widen_fwd(Seq& q, const float* Uin, int ldin, const int c0in[2], const int din[2], const float* const W[2],
                GroupCPtrs bias, RowGroups g, GroupPtrs yout, float* invn, long rows, int normalize);
 void gather_cols(Seq& q, const float* x0, int ld0, int w0, const float* x1, int ld1, int w1, float* out, long rows);
+bool scatter_add_cols_part_supported(int w0, int w1);
+void scatter_add_cols_part(Seq& q, const float* src, GroupPtrs d, GroupCPtrs xhat, int w0, int w1, int G, float* part,
+                           long rows);
 void scatter_add_cols(Seq& q, const float* src, float* d0, int ld0, int w0, float* d1, int ld1, int w1, long rows);
 void zero_fill(Seq& q, void* p, size_t bytes);   // wide-store zero kernel (byte kernel for odd sizes); never a memset node
 void zero_small(Seq& q, void* p, size_t bytes);

@@ -642,8 +642,26 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
             float* dxagg = dUj;                    // dV is consumed: its buffer takes A^T d(A x)
             aggregate(q, io.adj, Gj, cin, dxagg, cin, B, n, cin, true, 0.f, pk, vs, false);
             if (add_self) axpy(q, dxagg, Gj, 1.f, (long)B * n * cin);
-            scatter_add_cols(q, dxagg, gr.dZe + li.coff_e[l - 1], li.D, de, li.a ? gr.dZa + li.coff_a[l - 1] : nullptr,
-                             li.Da, da, (long)B * n);
+            if (bn && !knobs().no_rowpart_hook && scatter_add_cols_part_supported(de, da)) {
+                // ... and the BatchNorm-backward partials of layer l - 1, whose gradient these rows complete
+                GroupPtrs dd{};
+                GroupCPtrs xh{};
+                dd.p[0] = gr.dZe + li.coff_e[l - 1];
+                dd.ld[0] = li.D;
+                xh.p[0] = lv.Ze + li.coff_e[l - 1];
+                xh.ld[0] = li.D;
+                if (li.a) {
+                    dd.p[1] = gr.dZa + li.coff_a[l - 1];
+                    dd.ld[1] = li.Da;
+                    xh.p[1] = lv.Za + li.coff_a[l - 1];
+                    xh.ld[1] = li.Da;
+                }
+                scatter_add_cols_part(q, dxagg, dd, xh, de, da, li.G, part, (long)B * n);
+                part_ready = true;
+            } else {
+                scatter_add_cols(q, dxagg, gr.dZe + li.coff_e[l - 1], li.D, de,
+                                 li.a ? gr.dZa + li.coff_a[l - 1] : nullptr, li.Da, da, (long)B * n);
+            }
             continue;
         }
         // G = A^T dU (+ dU)

@@ -1786,6 +1786,41 @@ __global__ __launch_bounds__(256) void k_scatter_add_cols(const float* src, floa
         *d += src[e];
     }
 }
+// scatter_add_cols + the BatchNorm-backward partials of the rows it completes: one 16-lane team per (row, group),
+// widths <= 32.  d_g[row, :w_g] += src[row, c0_g : c0_g + w_g];  part[(row * G + g) * 2 + {0, 1}] = (sum v, sum v * xhat).
+__global__ __launch_bounds__(256) void k_scatter_add_cols_part(const float* src, GroupPtrs d, GroupCPtrs xhat, int w0,
+                                                               int w1, int G, float* part, long rows) {
+    const int tl = threadIdx.x & 15;
+    const long team = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long nteams = (long)gridDim.x * 16;
+    const int ws = w0 + w1;
+    for (long it = team; it < rows * G; it += nteams) {
+        const long row = it / G;
+        const int g = (int)(it % G);
+        const int w = g ? w1 : w0;
+        const float* s = src + row * ws + (g ? w0 : 0);
+        float* dd = d.p[g] + row * d.ld[g];
+        const float* xh = xhat.p[g] + row * xhat.ld[g];
+        const int c0 = min(tl, w - 1), c1 = min(tl + 16, w - 1);
+        const float a0 = s[c0], a1 = s[c1], b0 = dd[c0], b1 = dd[c1], x0 = xh[c0], x1 = xh[c1];
+        const float v0 = tl < w ? a0 + b0 : 0.f, v1 = tl + 16 < w ? a1 + b1 : 0.f;
+        if (tl < w) dd[tl] = v0;
+        if (tl + 16 < w) dd[tl + 16] = v1;
+        const float s0 = team_sum(v0 + v1), s1 = team_sum(v0 * x0 + v1 * x1);
+        if (tl == 0) {
+            part[it * 2] = s0;
+            part[it * 2 + 1] = s1;
+        }
+    }
+}
+bool scatter_add_cols_part_supported(int w0, int w1) { return w0 >= 1 && w0 <= 32 && w1 <= 32; }
+void scatter_add_cols_part(Seq& q, const float* src, GroupPtrs d, GroupCPtrs xhat, int w0, int w1, int G, float* part,
+                           long rows) {
+    if (!q.ok() || rows <= 0) return;
+    hipLaunchKernelGGL(k_scatter_add_cols_part, dim3(team_grid(rows * G)), dim3(256), 0, q.stream, src, d, xhat, w0, w1, G,
+                       part, rows);
+    q.check_launch("scatter_add_cols_part");
+}
 void gather_cols(Seq& q, const float* x0, int ld0, int w0, const float* x1, int ld1, int w1, float* out, long rows) {
     if (!q.ok() || rows <= 0) return;
     const long blocks = (rows * (w0 + w1) + 255) / 256;
