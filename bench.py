@@ -297,45 +297,6 @@ def mfma_probe(w, device, iters=50):
                 mfma_busy_pmc=pmc)
 
 
-def _collective_capture_works(dist, device, world, rank):
-    """Capture and replay one all-reduce on a throw-away communicator; True iff it ran and gave the right sum on
-    every rank."""
-    ok = 0.0
-    try:
-        grp = dist.new_group(ranks=list(range(world)), backend="nccl")
-        t = torch.full((1024,), float(rank + 1), device=device)
-        dist.all_reduce(t, group=grp)                       # communicator set-up happens eagerly
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream(device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            t.fill_(float(rank + 1))
-            dist.all_reduce(t, group=grp)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        t.fill_(float(rank + 1))
-        torch.cuda.synchronize()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            dist.all_reduce(t, group=grp)
-        t.fill_(float(rank + 1))
-        g.replay()
-        torch.cuda.synchronize()
-        ok = 1.0 if abs(float(t[0]) - world * (world + 1) / 2) < 1e-3 else 0.0
-    except Exception as e:                                   # noqa: BLE001
-        print(f"[bench] rank {rank}: a captured all-reduce is not available here ({type(e).__name__}: {e})",
-              file=sys.stderr)
-        ok = 0.0
-        try:
-            torch.cuda.synchronize()
-        except Exception:                                    # noqa: BLE001
-            pass
-    # every rank must take the same path
-    flag = torch.tensor([ok], device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    return bool(flag.item() > 0.5)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -400,7 +361,8 @@ def main():
     # one must survive to run the collective eagerly instead.  DP_BENCH_GRAPH_ALLREDUCE=0 skips the attempt.
     graph_allreduce = False
     if dp is not None and not rehearse and not args.no_graph and os.environ.get("DP_BENCH_GRAPH_ALLREDUCE", "1") != "0":
-        graph_allreduce = _collective_capture_works(dist, device, world, rank)
+        from graph_pooling_amd.parallel import collective_capture_works
+        graph_allreduce = collective_capture_works(device, world, rank)
         if rank == 0:
             print(f"[bench] gradient all-reduce {'inside' if graph_allreduce else 'outside'} the hipGraph",
                   file=sys.stderr)

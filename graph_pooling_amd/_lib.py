@@ -18,6 +18,8 @@ DP_MAX_PRED = 4
 
 F_ADD_SELF, F_NORMALIZE, F_RELU, F_BN, F_LAST_ONLY = 1, 2, 4, 8, 16
 MODE_EVAL, MODE_TRAIN = 0, 1
+ERR_DEVICE = -4                                   # DP_ERR_DEVICE
+DEVERR_BARRIER, DEVERR_NONFINITE_GRAD = 1, 2      # DP_DEVERR_*
 SAVE_S, SAVE_XPOOL, SAVE_ADJPOOL, SAVE_Z, SAVE_ZASSIGN, SAVE_ARGMAX = 0, 1, 2, 3, 4, 5
 
 
@@ -66,6 +68,8 @@ _Z = C.c_size_t
 _PROTOS = {
     "dp_version": (_I, []),
     "dp_last_error_string": (C.c_char_p, []),
+    "dp_device_error": (_I, [_I]),
+    "dp_device_error_describe": (C.c_char_p, [_I]),
     "dp_sizeof_encoder_cfg": (_Z, []),
     "dp_bgemm_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _F, _I, _P]),
     "dp_bgemm_split_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _P]),

@@ -44,8 +44,61 @@ const Knobs& knobs() {
         k.no_widen_fusion = getenv("DP_NO_WIDEN_FUSION") != nullptr;
         k.no_rowpart_hook = getenv("DP_NO_ROWPART_HOOK") != nullptr;
         k.no_row_quads = getenv("DP_NO_ROW_QUADS") != nullptr;
+        k.test_barrier_fail = getenv("DP_TEST_BARRIER_FAIL") != nullptr;
     });
     return k;
+}
+
+// ---- device-side failure word: one pinned, device-mapped host int per device ordinal (diffpool_hip.h)
+namespace {
+struct DevErrSlot {
+    std::once_flag once;
+    int* host = nullptr;
+    int* dev = nullptr;
+};
+DevErrSlot g_dev_err[64];
+DevErrSlot* dev_err_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+    DevErrSlot& s = g_dev_err[d];
+    std::call_once(s.once, [&s] {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
+        memset(h, 0, 64);
+        void* dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+        s.host = (int*)h;
+        s.dev = (int*)dv;
+    });
+    return s.host ? &s : nullptr;
+}
+}  // namespace
+int* device_error_word() {
+    DevErrSlot* s = dev_err_slot();
+    return s ? s->dev : nullptr;
+}
+int device_error_take(bool clear) {
+    DevErrSlot* s = dev_err_slot();
+    if (!s) return 0;
+    return clear ? __atomic_exchange_n(s->host, 0, __ATOMIC_ACQ_REL) : __atomic_load_n(s->host, __ATOMIC_ACQUIRE);
+}
+static const char* device_error_text(int mask) {
+    if ((mask & DP_DEVERR_BARRIER) && (mask & DP_DEVERR_NONFINITE_GRAD))
+        return "a whole-level kernel's grid barrier gave up (its workgroups were not co-resident: is the device shared? "
+               "set DP_NO_LEVEL_FUSION=1) and dp_clip_adam_step refused the resulting non-finite gradients";
+    if (mask & DP_DEVERR_BARRIER)
+        return "a whole-level kernel's grid barrier gave up: its workgroups were not co-resident (is the device shared "
+               "with another process or stream? set DP_NO_LEVEL_FUSION=1); that step's outputs are NaN";
+    if (mask & DP_DEVERR_NONFINITE_GRAD)
+        return "dp_clip_adam_step met a non-finite gradient norm and skipped the update (parameters untouched)";
+    return mask ? "unknown device error bits" : "no device error";
+}
+int device_error_gate(const char* entry) {
+    const int m = device_error_take(false);
+    if (!m) return DP_OK;
+    device_error_take(true);
+    set_error("%s: a kernel of an EARLIER call on this device failed (mask %d): %s", entry, m, device_error_text(m));
+    return DP_ERR_DEVICE;
 }
 
 void ensure_dyn_lds(Seq& q, DynLdsOnce& st, const void* fn, int bytes, const char* what) {
@@ -273,6 +326,13 @@ extern "C" {
 
 int dp_version(void) { return DP_VERSION; }
 const char* dp_last_error_string(void) { return dp::last_error(); }
+int dp_device_error(int clear) { return device_error_take(clear != 0); }
+const char* dp_device_error_describe(int mask) { return device_error_text(mask); }
+#define DEVICE_GATE(name)                                     \
+    do {                                                      \
+        const int gate_rc_ = device_error_gate(name);         \
+        if (gate_rc_ != DP_OK) return gate_rc_;               \
+    } while (0)
 
 int dp_bgemm_f32(const float* A, const float* B, float* C, const float* bias, int batch, int M, int N, int K,
                  int lda, int ldb, int ldc, long strideA, long strideB, long strideC, int transA, int transB,
@@ -643,6 +703,7 @@ int dp_encoder_forward(const dp_encoder_cfg* cfg, const float* params, const flo
     DP_CHECK_ARG(cfg->num_pooling == 0 || assign_x, "assign_x is NULL");
     DP_CHECK_ARG(save_bytes >= encoder_save_bytes(*cfg), "save buffer too small: %zu < %zu", save_bytes,
                  encoder_save_bytes(*cfg));
+    DEVICE_GATE("dp_encoder_forward");
     Seq q(STREAM(stream), workspace, workspace_bytes);
     DP_CHECK_ARG((mode & ~(DP_MODE_TRAIN)) == 0, "mode=%d: DP_MODE_EVAL or DP_MODE_TRAIN", mode);
     return encoder_forward(q, *cfg, params, x, adj, assign_x, num_nodes, dropout, ypred, assign_out, save, mode,
@@ -657,6 +718,7 @@ int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const fl
     NOTNULL(params); NOTNULL(x); NOTNULL(adj); NOTNULL(d_ypred); NOTNULL(grads); NOTNULL(save);
     DP_CHECK_ARG(save_bytes >= encoder_save_bytes(*cfg), "save buffer too small: %zu < %zu", save_bytes,
                  encoder_save_bytes(*cfg));
+    DEVICE_GATE("dp_encoder_backward");
     Seq q(STREAM(stream), workspace, workspace_bytes);
     return encoder_backward(q, *cfg, params, x, adj, assign_x, num_nodes, dropout, d_ypred, d_assign, grads, save,
                             prezeroed);
@@ -673,6 +735,7 @@ int dp_loss_forward(const float* ypred, const long long* label, const float* S, 
     NOTNULL(ypred); NOTNULL(label); NOTNULL(loss_out); NOTNULL(prob);
     NONNEG(B); NONNEG(C);
     DP_CHECK_ARG(!linkpred || (S && adj && N > 0 && K > 0), "linkpred needs S, adj, N, K");
+    DEVICE_GATE("dp_loss_forward");
     Seq q(STREAM(stream), workspace, workspace_bytes);
     loss_fwd_seq(q, ypred, label, S, adj, num_nodes, link_norm, loss_out, prob, d_ypred_unit, B, C, N, K, linkpred);
     return q.err;
@@ -683,6 +746,7 @@ int dp_loss_backward(const float* prob, const long long* label, const float* S, 
     NOTNULL(prob); NOTNULL(label);
     NONNEG(B); NONNEG(C);
     DP_CHECK_ARG(!linkpred || (S && adj && dS && N > 0 && K > 0), "linkpred needs S, adj, dS, N, K");
+    DEVICE_GATE("dp_loss_backward");
     Seq q(STREAM(stream), workspace, workspace_bytes);
     loss_bwd_seq(q, prob, label, S, adj, num_nodes, link_norm, dloss, d_ypred, dS, B, C, N, K, linkpred);
     return q.err;
@@ -716,6 +780,7 @@ int dp_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_av
     DP_CHECK_ARG(step >= 1, "step=%d is the 1-based count of this update", step);
     DP_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "betas (%g, %g) must lie in [0, 1)",
                  (double)beta1, (double)beta2);
+    DEVICE_GATE("dp_clip_adam_step");
     Seq q(STREAM(stream), workspace, workspace_bytes);
     // bias corrections in double on the host, exactly as torch.optim.Adam's single-tensor path computes them
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);

@@ -24,6 +24,18 @@ const char* last_error();
         }                                            \
     } while (0)
 
+// ----------------------------------------------------------------- device-side failures (see diffpool_hip.h)
+// Device-visible pointer to the current device's error word (pinned, mapped host memory; nullptr when it could not be
+// set up — kernels test for null), and the host-side read.  Kernels raise a bit with dev_err_raise().
+int* device_error_word();
+int device_error_take(bool clear);            // DP_DEVERR_* mask of the current device
+int device_error_gate(const char* entry);     // DP_OK, or DP_ERR_DEVICE (+ message, word cleared) when a bit is pending
+#ifdef __HIPCC__
+__device__ inline void dev_err_raise(int* word, int bit) {
+    if (word) __hip_atomic_fetch_or(word, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
 // ----------------------------------------------------------------- cross-lane reductions on DPP
 // __shfl_xor compiles to ds_bpermute_b32 (an LDS-pipe round trip per step); these run in the VALU.  A DPP row is 16
 // lanes: two quad permutes, then the half-row and the row mirror, leave the row's total in every lane.  The wave
@@ -140,6 +152,8 @@ struct Knobs {
     bool no_rowpart_hook;  // DP_NO_ROWPART_HOOK: BatchNorm-backward partials in a launch of their own
     bool no_widen_fusion;  // DP_NO_WIDEN_FUSION: widening layers' row-local products on the GEMM kernels
     bool no_agg_first;     // DP_NO_AGG_FIRST: every GraphConv as A (x W), also the layers that widen a lot
+    bool test_barrier_fail;  // DP_TEST_BARRIER_FAIL: TEST ONLY — grid barriers wait for one arrival too many with a
+                             // tiny spin limit, so the give-up path runs (tests/test_gpu_edge_cases.py)
 };
 const Knobs& knobs();
 

@@ -209,7 +209,8 @@ int validate(const dp_encoder_cfg* c) {
     DP_CHECK_ARG(c->n_graph_params >= 0 && c->n_graph_params <= c->n_params, "n_graph_params out of range");
     DP_CHECK_ARG(c->bn_world >= 0 && c->bn_world <= 1024, "bn_world=%d out of range", c->bn_world);
     DP_CHECK_ARG(c->bn_world <= 1 || c->exchange, "bn_world=%d needs the exchange callback", c->bn_world);
-    DP_CHECK_ARG(c->bn_world <= 1 || c->readout == 0, "sync-BN is implemented for the max-readout encoders");
+    DP_CHECK_ARG(!(c->bn_world > 1 || (c->bn_world == 1 && c->exchange)) || c->readout == 0,
+                 "sync-BN is implemented for the max-readout encoders");
     return DP_OK;
 }
 
@@ -272,9 +273,12 @@ BwdZero alloc_bwd_zero(Seq& q, const dp_encoder_cfg& c) {
 // The one-workgroup-per-graph kernels and the whole-level kernels combine partials inside the launch, so they are
 // not used in this mode: all levels run on the generic per-layer kernels.
 inline int bn_world(const dp_encoder_cfg& c) { return c.bn_world > 1 ? c.bn_world : 1; }
+// bn_world == 1 WITH an exchange callback is sync-BN over a single rank: the same launch sequence and the same
+// callbacks as W > 1 (what a one-GPU box can execute of the RCCL path), statistics over the local batch
+inline bool bn_sync(const dp_encoder_cfg& c) { return c.bn_world > 1 || (c.bn_world == 1 && c.exchange != nullptr); }
 // local [B, n, G, 2] block -> gathered [world * B, n, G, 2]; returns the pointer the consumer should read
 const float* bn_exchange(Seq& q, const dp_encoder_cfg& c, const float* local, float* gathered, size_t floats) {
-    if (bn_world(c) == 1) return local;
+    if (!bn_sync(c)) return local;
     if (!q.ok()) return gathered;
     const int rc = c.exchange(c.exchange_user, local, gathered, floats * sizeof(float), (void*)q.stream);
     if (rc != 0) {
@@ -402,12 +406,12 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
     const int W = bn_world(c);
-    if (W == 1 && bar && level_is_fused(c, li, io, true)) {
+    if (!bn_sync(c) && bar && level_is_fused(c, li, io, true)) {
         small_level_fwd(q, small_level_io(li, lv, io, params, lvl_part, bar), B, n, li.e->dims, li.L, add_self ? 1 : 0,
                         bn ? 1 : 0);
         return;
     }
-    if (W == 1 && level_is_small(B, li) && !level_has_dropout(li, io)) {
+    if (!bn_sync(c) && level_is_small(B, li) && !level_has_dropout(li, io)) {
         // pooled level (or tiny graphs): one launch per layer, one workgroup per graph (dp_small.hip)
         float* pbuf[2] = {part, part_b};
         for (int l = 0; l < li.L; ++l) {
@@ -518,7 +522,7 @@ void level_forward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const L
             // apply_bn and the NEXT layer's transform in one launch when that transform is a plain row-local product
             const RowGroups gnext = groups_of(li, l + 1);
             const float* part_r = bn ? bn_exchange(q, c, part, part_all, (size_t)B * n * li.G * 2) : nullptr;
-            bool plain_next = W == 1 && !knobs().no_level_fusion && bn_transform_supported(g, gnext, B) &&
+            bool plain_next = !bn_sync(c) && !knobs().no_level_fusion && bn_transform_supported(g, gnext, B) &&
                               !layer_agg_first(li, l + 1);
             for (int gi = 0; gi < li.G; ++gi) plain_next = plain_next && !drop_mask(li, io, gi, l + 1);
             if (plain_next) {
@@ -545,12 +549,12 @@ void level_backward(Seq& q, const dp_encoder_cfg& c, const LevelInfo& li, const 
     const int ks_level = n >= 256 ? KS : 1;
     const bool bn = c.flags & DP_F_BN;
     const bool add_self = c.flags & DP_F_ADD_SELF;
-    if (W == 1 && lvl_part && bar && level_is_fused(c, li, io, true)) {
+    if (!bn_sync(c) && lvl_part && bar && level_is_fused(c, li, io, true)) {
         small_level_bwd(q, small_level_io(li, lv, io, params, lvl_part, bar), gr.dZe, gr.dX0, gr.dAdj, slabs, gstride,
                         B, n, li.e->dims, li.L, add_self ? 1 : 0, bn ? 1 : 0);
         return;
     }
-    if (W == 1 && level_is_small(B, li) && !level_has_dropout(li, io)) {
+    if (!bn_sync(c) && level_is_small(B, li) && !level_has_dropout(li, io)) {
         float* pbuf[2] = {part, part_b};
         for (int l = li.L - 1; l >= 0; --l) {
             const bool last = l == li.L - 1;
@@ -830,7 +834,7 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
     s.part_b = q.alloc<float>(maxPart);
     s.logits = q.alloc<float>(maxLog > 0 ? maxLog : 1);
     s.lvl_part = q.alloc<float>(level_part_floats(c));
-    s.part_all = bn_world(c) > 1 ? q.alloc<float>(maxPart * bn_world(c)) : nullptr;
+    s.part_all = bn_sync(c) ? q.alloc<float>(maxPart * bn_world(c)) : nullptr;
     s.vs = q.alloc<unsigned short>(vs_elems(c));
     const size_t dsf = dropout_scratch_floats(c);
     s.xm[0] = dsf ? q.alloc<float>(dsf) : nullptr;
@@ -989,7 +993,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     float* part = q.alloc<float>(maxPart);
     float* part_b = q.alloc<float>(maxPart);
     float* lvl_part = q.alloc<float>(level_part_floats(c));
-    float* part_all = bn_world(c) > 1 ? q.alloc<float>(maxPart * bn_world(c)) : nullptr;
+    float* part_all = bn_sync(c) ? q.alloc<float>(maxPart * bn_world(c)) : nullptr;
     unsigned short* vs = q.alloc<unsigned short>(vs_elems(c));
     float* dS = q.alloc<float>(maxSK ? maxSK : 1);
     float* dlog = q.alloc<float>(maxSK ? maxSK : 1);

@@ -4,6 +4,9 @@
 // a fixed order so the result is deterministic), one pass that every workgroup starts by folding those partials
 // into the clip coefficient and then applies to its slice:  g *= min(1, max_norm / (||g|| + 1e-6));  Adam with the
 // bias corrections folded into step_size = lr / (1 - b1^t) and 1 / sqrt(1 - b2^t) by the host (as torch does).
+// A NON-FINITE gradient norm (a poisoned backward pass, diffpool_hip.h "Device-side failures") skips the whole update —
+// parameters, moments and gradients stay as they are — and raises DP_DEVERR_NONFINITE_GRAD; torch would write NaN
+// into every parameter (clip_grad_norm_ with its default error_if_nonfinite=False, then Adam).
 #include "dp_common.h"
 
 namespace dp {
@@ -22,7 +25,8 @@ __global__ __launch_bounds__(256) void k_sqnorm_partials(const float* g, long n,
 
 __global__ __launch_bounds__(256) void k_clip_adam(float* p, float* g, float* m, float* v, long n, const float* partial,
                                                    int npartial, float max_norm, float beta1, float beta2, float eps,
-                                                   float step_size, float inv_bc2_sqrt, float* total_norm_out) {
+                                                   float step_size, float inv_bc2_sqrt, float* total_norm_out,
+                                                   int* dev_err) {
     __shared__ float coef_s;
     if (threadIdx.x < 64) {
         float s = 0.f;
@@ -33,12 +37,17 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* p, float* g, float* m,
             const float tn = sqrtf(s);
             float c = 1.f;
             if (partial && max_norm > 0.f) c = fminf(max_norm / (tn + 1e-6f), 1.f);
+            if (partial && !isfinite(tn)) {
+                c = __builtin_nanf("");
+                if (blockIdx.x == 0) dev_err_raise(dev_err, DP_DEVERR_NONFINITE_GRAD);
+            }
             coef_s = c;
             if (blockIdx.x == 0 && total_norm_out) total_norm_out[0] = tn;
         }
     }
     __syncthreads();
     const float coef = coef_s;
+    if (coef != coef) return;          // non-finite gradient norm: no update
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gi = g[i] * coef;
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;
@@ -63,7 +72,7 @@ void clip_adam_step(Seq& q, float* params, float* grads, float* exp_avg, float* 
     }
     hipLaunchKernelGGL(k_clip_adam, dim3(wgs), dim3(256), 0, q.stream, params, grads, exp_avg, exp_avg_sq, n,
                        need_norm ? partial : (const float*)nullptr, wgs, max_norm, beta1, beta2, eps, step_size,
-                       inv_bc2_sqrt, total_norm_out);
+                       inv_bc2_sqrt, total_norm_out, device_error_word());
     q.check_launch("clip_adam");
 }
 

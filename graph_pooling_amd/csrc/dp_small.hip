@@ -504,17 +504,19 @@ __device__ inline void sm_st_agent(float* p, float v) {
 __device__ inline float sm_ld_agent(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// returns false when the wait gave up.  `flag` is an LDS word.
-__device__ inline bool sm_grid_barrier(int* bar, int target, int* flag) {
+// returns false when the wait gave up (and raises DP_DEVERR_BARRIER in the device's error word, which the next
+// model-level entry reports: diffpool_hip.h "Device-side failures").  `flag` is an LDS word.
+__device__ inline bool sm_grid_barrier(int* bar, int target, int* flag, int spin_limit, int* dev_err) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's exchange stores are acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(bar, 1, SM_BAR_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         int it = 0, ok = 1;
         while (__hip_atomic_load(bar, SM_BAR_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++it > SM_SPIN_LIMIT) {
+            if (++it > spin_limit) {
                 ok = 0;
                 __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dev_err_raise(dev_err, DP_DEVERR_BARRIER);
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -542,6 +544,8 @@ struct SmallLevelFwdArgs {
     int coff[DP_MAX_LAYERS];
     float* part;                   // exchange: [L-1][B][n][2] (row mean, row M2) of relu(y)
     int* bar;                      // bar[0] ticket (zero at launch), bar[1] error word
+    int* dev_err;                  // the device's host-visible error word (or null)
+    int spin_limit, target_bias;   // SM_SPIN_LIMIT, 0 (the test knob DP_TEST_BARRIER_FAIL: 64, 1)
     int B, n, add_self, bn;
     int dmax, omax, wtot, btot;    // max layer input width, max output width, total weight / bias floats
     SmDiv qd0;
@@ -645,7 +649,7 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
         if (last) break;
         if (stats) {
             // every graph's partials of this layer, then the statistics per node index (Chan combine)
-            const bool ok = sm_grid_barrier(a.bar, (l + 1) * a.B, &bar_ok);
+            const bool ok = sm_grid_barrier(a.bar, (l + 1) * a.B + a.target_bias, &bar_ok, a.spin_limit, a.dev_err);
             SM_STAMP(0, 13 + 6 * l);
             // one 16-lane team per node index: its B (mean, M2) pairs straight from the exchange buffer, one round trip
             for (int r = team; r < n; r += NTEAMS) {
@@ -721,6 +725,8 @@ struct SmallLevelBwdArgs {
     long slab_stride;
     float* part;                       // exchange: [L-1][B][n][2] (sum dx, sum dx * xhat)
     int* bar;
+    int* dev_err;
+    int spin_limit, target_bias;
     int B, n, add_self, bn;
     int omax, wtot, D;                 // max layer output width, total weight floats, concat width
     SmDiv qd0, qD;
@@ -814,7 +820,7 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
                 }
             }
             ++nbar;
-            const bool ok = sm_grid_barrier(a.bar, nbar * a.B, &bar_ok);
+            const bool ok = sm_grid_barrier(a.bar, nbar * a.B + a.target_bias, &bar_ok, a.spin_limit, a.dev_err);
             for (int r = team; r < n; r += NTEAMS) {
                 float p0[SM_BMAX16], p1[SM_BMAX16];
 #pragma unroll
@@ -1001,6 +1007,29 @@ static int device_cus() {
     }
     return v > 0 ? v : 0;
 }
+// The runtime admits at least one 1024-thread workgroup of each whole-level kernel per CU at the LDS size they are
+// launched with (asked once per device; a kernel that could not be resident at all must never meet a grid barrier).
+static bool level_kernels_admitted() {
+    static std::atomic<int> state[64];      // 0 unknown, 1 yes, -1 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int v = state[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        v = 1;
+        const void* fns[2] = {reinterpret_cast<const void*>(&k_small_level_fwd),
+                              reinterpret_cast<const void*>(&k_small_level_bwd)};
+        for (const void* fn : fns) {
+            int blocks = 0;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 1024, 150 * 1024) != hipSuccess || blocks < 1) {
+                (void)hipGetLastError();
+                v = -1;
+            }
+        }
+        state[dev].store(v, std::memory_order_relaxed);
+    }
+    return v > 0;
+}
 // All layers of the level in one launch: shapes the kernels take AND a batch whose workgroups are certainly
 // co-resident (one 1024-thread workgroup per CU; half the CUs is the margin for a partitioned or shared device).
 bool small_level_fused_ok(int B, int n, const int* dims, int L, bool dadj) {
@@ -1010,7 +1039,7 @@ bool small_level_fused_ok(int B, int n, const int* dims, int L, bool dadj) {
     if (small_level_lds_fwd(B, n, dims, L) * sizeof(float) > 150 * 1024) return false;
     if (small_level_lds_bwd(B, n, dims, L, dadj) * sizeof(float) > 150 * 1024) return false;
     const int cus = device_cus();
-    return cus > 0 && B <= cus / 2 && B <= 16 * SM_BMAX16;
+    return cus > 0 && B <= cus / 2 && B <= 16 * SM_BMAX16 && level_kernels_admitted();
 }
 size_t small_level_part_floats(int B, int n, int L) { return (size_t)(L > 1 ? L - 1 : 1) * B * n * 2; }
 
@@ -1034,6 +1063,9 @@ void small_level_fwd(Seq& q, const SmallLevelIO& io, int B, int n, const int* di
         a.btot += dims[l + 1];
     }
     a.qd0 = sm_div(dims[0]);
+    a.dev_err = device_error_word();
+    a.spin_limit = knobs().test_barrier_fail ? 64 : SM_SPIN_LIMIT;
+    a.target_bias = knobs().test_barrier_fail ? 1 : 0;
     hipLaunchKernelGGL(k_small_level_fwd, dim3(B), dim3(1024), small_level_lds_fwd(B, n, dims, L) * sizeof(float),
                        q.stream, a);
     q.check_launch("small_level_fwd");
@@ -1062,6 +1094,9 @@ void small_level_bwd(Seq& q, const SmallLevelIO& io, const float* dZe, float* dX
     }
     a.qd0 = sm_div(dims[0]);
     a.qD = sm_div(a.D);
+    a.dev_err = device_error_word();
+    a.spin_limit = knobs().test_barrier_fail ? 64 : SM_SPIN_LIMIT;
+    a.target_bias = knobs().test_barrier_fail ? 1 : 0;
     hipLaunchKernelGGL(k_small_level_bwd, dim3(B), dim3(1024),
                        small_level_lds_bwd(B, n, dims, L, dadj != nullptr) * sizeof(float), q.stream, a);
     q.check_launch("small_level_bwd");

@@ -193,7 +193,7 @@ class _Plan:
         self.cfg = owner._build_cfg(B, N)
         self._exchange_cb = None
         sync = getattr(owner, "_sync_bn", None)
-        if sync is not None and sync.world > 1:
+        if sync is not None and sync.active:
             # sync-BN: the library calls back between the launch that writes a BatchNorm site's local row partials
             # and the launch that combines them; both blocks live inside this plan's workspace
             def exchange(_user, local, gathered, nbytes, _stream, plan=self, sync=sync):
@@ -205,7 +205,7 @@ class _Plan:
                     sync.all_gather(dst, src)
                     return 0
                 except Exception as e:      # noqa: BLE001 — never let an exception unwind through the C frames
-                    sync.error = e
+                    sync.fail(e)            # peers are blocked in the same collective: abort the group, then raise
                     return 1
             self._exchange_cb = _lib.EXCHANGE_FN(exchange)
             self.cfg.bn_world = sync.world
@@ -536,9 +536,9 @@ _UNIT_SEED = {}          # device -> the scalar 1.0 that seeds loss.backward()
 
 def _unit_seed(device):
     """A cached device scalar 1.0.  `loss.backward()` (train.py:208) seeds the backward pass with ones_like(loss) — a
-    fill launch per step; `_Loss.backward` hands autograd this tensor instead, and `_LossFn.backward` recognises it by
-    address, so the gradient (softmax - onehot) / B that the loss kernel already wrote goes to the prediction head
-    as it is: no seed fill, no cross-entropy backward launch."""
+    fill launch per step; `_Loss.backward` hands autograd this tensor instead and ARMS the loss node (see _Loss), so
+    the gradient (softmax - onehot) / B that the loss kernel already wrote goes to the prediction head as it is: no
+    seed fill, no cross-entropy backward launch."""
     t = _UNIT_SEED.get(device)
     if t is None:
         if device.type != "cuda" or torch.cuda.is_current_stream_capturing():
@@ -550,19 +550,33 @@ def _unit_seed(device):
 
 class _Loss(torch.Tensor):
     """The loss tensor `model.loss()` returns: an ordinary tensor whose parameterless `.backward()` seeds autograd with
-    the cached unit scalar (see _unit_seed).  Every other operation returns plain tensors."""
+    the cached unit scalar (see _unit_seed) and tells the loss node so EXPLICITLY: `_dp_node` is the _LossFn backward
+    node of this very tensor, and `unit_armed` is set on it only for the duration of a root `.backward()` with no
+    `gradient=` — the one situation in which the upstream gradient is exactly 1.  Anything else — `(loss * 1)
+    .backward()`, `loss.backward(gradient=g)`, `torch.autograd.grad(loss, ...)` — never arms the node and takes the
+    general path (tests/test_gpu_model.py::test_loss_backward_fast_path_equals_every_other_way_of_calling_it).  Every
+    other operation returns plain tensors."""
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         with torch._C.DisableTorchFunctionSubclass():
+            node = None
             if func is torch.Tensor.backward and len(args) == 1 and kwargs.get("gradient") is None \
-                    and args[0].dim() == 0 and args[0].dtype == torch.float32:
-                seed = _unit_seed(args[0].device)
+                    and isinstance(args[0], _Loss) and args[0].dim() == 0 and args[0].dtype == torch.float32:
+                node = getattr(args[0], "_dp_node", None)
+                seed = _unit_seed(args[0].device) if node is not None else None
                 if seed is not None:
                     kwargs = dict(kwargs)
                     kwargs["gradient"] = seed
-            return func(*args, **kwargs)
+                    node.unit_armed = True
+                else:
+                    node = None
+            try:
+                return func(*args, **kwargs)
+            finally:
+                if node is not None:
+                    node.unit_armed = False
 
 
 class _LossFn(torch.autograd.Function):
@@ -603,8 +617,7 @@ class _LossFn(torch.autograd.Function):
         B, Cc, N, K, linkpred = ctx.dims
         if dtotal is None:
             return None, None, None, None, None, None, None
-        seed = _UNIT_SEED.get(dtotal.device)
-        unit = seed is not None and dtotal.data_ptr() == seed.data_ptr() and dtotal.dim() == 0
+        unit = bool(getattr(ctx, "unit_armed", False))     # armed by _Loss.backward: the upstream gradient is exactly 1
         if unit and not linkpred:
             return dunit, None, None, None, None, None, None     # written by the loss kernel: nothing to launch
         dtotal = dtotal.contiguous().float()
@@ -623,7 +636,7 @@ def _loss(owner, pred, label, S, adj, batch_num_nodes, linkpred):
     nn_dev = _num_nodes_device(batch_num_nodes, pred.device) if linkpred else None
     link_norm = None
     sync = getattr(owner, "_sync_bn", None)
-    if linkpred and sync is not None and sync.world > 1:
+    if linkpred and sync is not None and sync.active:
         # the link loss divides by sum_b n_b^2 over the WHOLE batch (encoders.py:1326,1331): every rank uses
         # (global sum) / world, so the mean over ranks of the per-rank terms is the single-batch loss
         n_eff = nn_dev.clamp(max=S.shape[1]).float() if nn_dev is not None else \
@@ -633,7 +646,12 @@ def _loss(owner, pred, label, S, adj, batch_num_nodes, linkpred):
     if linkpred:
         owner.link_loss = link
     _unit_seed(pred.device)                   # make sure the cached seed exists before anyone captures a graph
-    return total.as_subclass(_Loss) if total.requires_grad else total
+    if not total.requires_grad:
+        return total
+    node = total.grad_fn                      # the _LossFn backward node (== the ctx its backward() receives)
+    out = total.as_subclass(_Loss)
+    out._dp_node = node
+    return out
 
 
 # ----------------------------------------------------------------------------- Set2Set encoder

@@ -35,11 +35,11 @@ class SupervisedGraphSage(nn.Module):
         return F.cross_entropy
 
     def forward(self, nodes) -> Tensor:
+        from . import _lib
+        from .sparse import hip_linear
         emb = self.enc(nodes)
-        if emb.is_cuda:                       # the library's fp32 MFMA GEMM (scores = emb @ weight)
-            from .sparse import hip_linear
-            return hip_linear(emb, self.weight.t())
-        return torch.matmul(emb, self.weight)
+        _lib.require_gpu_tensor(emb, "enc(nodes)")            # no CPU path, like every other module of the package
+        return hip_linear(emb, self.weight.t())               # the library's fp32 MFMA GEMM (scores = emb @ weight)
 
     def loss(self, nodes, labels: Tensor) -> Tensor:
         target = labels.reshape(-1).to(dtype=torch.long)

@@ -14,8 +14,12 @@ BatchNorm: apply_bn normalises per node index over the whole 
   * sync_bn=True (parity): every BatchNorm site all-gathers its per-row partials (mean, M2 forward;
     sum dx, sum dx*xhat backward: [B, n, G, 2] floats, 80 KB at the DD shape) before combining them, and the
     link loss is normalised by the global sum of n_b^2 — the averaged gradients are then those of ONE
-    reference step on the concatenated batch (checked against the oracle on the GPU box with two ranks,
-    tests/test_gpu_parallel.py).  Costs 2 (L-1) (1 + 2P) extra small collectives per step.
+    reference step on the concatenated batch.  Costs 2 (L-1) (1 + 2P) extra small collectives per step.
+
+What has run where (tests/test_gpu_parallel.py): parity of both modes against the oracle is pinned with TWO ranks over
+GLOO sharing the box's one GPU (RCCL refuses two ranks per device), at a small, a packed and the DD shard shape.  The
+RCCL branches (ReduceOp.AVG, all_gather_into_tensor, a collective captured into the step's hipGraph) have run with ONE
+rank only (`force=True` below keeps every collective on at world size 1); no multi-rank RCCL run exists yet.
 """
 from __future__ import annotations
 
@@ -33,9 +37,13 @@ class DataParallelEncoder:
     """
 
     def __init__(self, model, process_group: Optional[dist.ProcessGroup] = None, broadcast: bool = True,
-                 sync_bn: bool = False):
+                 sync_bn: bool = False, force: bool = False):
+        """force=True keeps every collective path on at world size 1 (the parameter broadcast, the gradient
+        all-reduce, the sync-BN all-gathers and the link-normaliser all-reduce all execute, over one rank): the way to
+        run the RCCL code on a one-GPU box."""
         self.model = model
         self.group = process_group
+        self.force = bool(force) and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # How the mean over ranks is formed is decided ONCE, here, identically on every rank: RCCL averages inside
         # the all-reduce (ncclAvg), gloo (CPU tests, one-GPU rehearsals) has no AVG -> SUM, then one scale.  A failing
@@ -48,10 +56,10 @@ class DataParallelEncoder:
                   f"BatchNorm statistics {'synchronised' if sync_bn else 'local to a rank'}", flush=True)
         device = next(model.parameters()).device
         model._ensure_flat(device)
-        if sync_bn and self.world > 1:
-            model._sync_bn = SyncBatchNormExchange(process_group, self.world)
+        if sync_bn and (self.world > 1 or self.force):
+            model._sync_bn = SyncBatchNormExchange(process_group, self.world, force=self.force)
             model._plans = {}                       # plans built before carry no exchange callback
-        if broadcast and self.world > 1:
+        if broadcast and (self.world > 1 or self.force):
             self.sync_parameters()
 
     def __getattr__(self, name):
@@ -85,7 +93,7 @@ class DataParallelEncoder:
 
     def reduce_gradients(self):
         """Average gradients over ranks with ONE all-reduce of the flat buffer."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         m = self.model
         flat = self._aliased_flat_grad()
@@ -110,10 +118,23 @@ class SyncBatchNormExchange:
     """The collectives of sync-BN mode, called from inside dp_encoder_forward / backward through the plan's exchange
     callback (encoders._Plan): an all-gather of a BatchNorm site's row partials on the current stream."""
 
-    def __init__(self, group, world):
+    def __init__(self, group, world, force=False):
         self.group, self.world = group, world
+        self.active = world > 1 or force          # force: the collectives run over a single rank too
         self.error = None
         self.calls = 0
+
+    def fail(self, exc):
+        """A collective raised inside the library's callback: the peers are (or will be) blocked in the same
+        collective, so this rank must not carry on as if it could recover.  Record the error, abort the process group
+        so the peers' collectives fail instead of hanging, and let the caller raise.  Never retried."""
+        self.error = exc
+        try:
+            abort = getattr(dist.distributed_c10d, "_abort_process_group", None)
+            if abort is not None:
+                abort(self.group)
+        except Exception:          # noqa: BLE001 — the abort is best effort; the original error is what gets reported
+            pass
 
     def all_gather(self, dst, src):
         # rank-major = batch-major: rank r's block lands at rows [r * B, (r + 1) * B) of the gathered partials
@@ -126,6 +147,46 @@ class SyncBatchNormExchange:
     def all_reduce_sum(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+
+def collective_capture_works(device, world: int, rank: int) -> bool:
+    """Capture and replay one all-reduce on a throw-away RCCL communicator; True iff it ran and gave the right sum on
+    every rank.  A failed capture can leave a communicator unusable, so the attempt is made on a group of its own: the
+    real one survives to run the collective eagerly.  Every rank takes the same answer (MIN over ranks)."""
+    import sys
+    ok = 0.0
+    try:
+        grp = dist.new_group(ranks=list(range(world)), backend="nccl")
+        t = torch.full((1024,), float(rank + 1), device=device)
+        dist.all_reduce(t, group=grp)                       # communicator set-up happens eagerly
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            t.fill_(float(rank + 1))
+            dist.all_reduce(t, group=grp)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        t.fill_(float(rank + 1))
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            dist.all_reduce(t, group=grp)
+        t.fill_(float(rank + 1))
+        g.replay()
+        torch.cuda.synchronize()
+        ok = 1.0 if abs(float(t[0]) - world * (world + 1) / 2) < 1e-3 else 0.0
+    except Exception as e:                                   # noqa: BLE001
+        print(f"[graph_pooling_amd.parallel] rank {rank}: a captured all-reduce is not available here "
+              f"({type(e).__name__}: {e})", file=sys.stderr)
+        ok = 0.0
+        try:
+            torch.cuda.synchronize()
+        except Exception:                                    # noqa: BLE001
+            pass
+    flag = torch.tensor([ok], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() > 0.5)
 
 
 def shard_batch(batch: dict, rank: int, world: int) -> dict:

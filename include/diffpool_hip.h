@@ -36,6 +36,7 @@ extern "C" {
 #define DP_ERR_INVALID_ARG (-1)
 #define DP_ERR_WORKSPACE (-2)
 #define DP_ERR_UNSUPPORTED (-3)
+#define DP_ERR_DEVICE (-4)      /* a kernel enqueued by an EARLIER call on this device reported a failure */
 
 /* layer flags */
 #define DP_F_ADD_SELF 1   /* y += x before the weight (GraphConv add_self, encoders.py:966-967) */
@@ -50,6 +51,24 @@ extern "C" {
 
 int dp_version(void);
 const char* dp_last_error_string(void);
+
+/* Device-side failures.  Calls only ENQUEUE work, so a failure inside a kernel cannot be the return value of the call
+ * that launched it.  Such a kernel raises a bit in a per-device word that lives in pinned, device-mapped HOST memory
+ * (64 bytes per device, allocated on first use; the one allocation this library makes — no device memory, no sync):
+ *   DP_DEVERR_BARRIER         a whole-level kernel's grid barrier gave up (its workgroups were not co-resident: the
+ *                             device is shared with another process / stream).  The kernel also poisons its BatchNorm
+ *                             statistics with NaN, so the step's outputs and gradients are NaN, never plausible.
+ *   DP_DEVERR_NONFINITE_GRAD  dp_clip_adam_step met a non-finite gradient norm and SKIPPED the update (parameters and
+ *                             moments untouched) — which is also what keeps a poisoned backward from ruining them.
+ * The NEXT model-level entry on that device (dp_encoder_forward / _backward, dp_loss_forward / _backward,
+ * dp_clip_adam_step) finds the word set, clears it, returns DP_ERR_DEVICE before launching anything and describes it
+ * in dp_last_error_string().  dp_device_error(clear) reads the current device's word directly (after a stream or
+ * device synchronisation it is up to date); dp_device_error_describe(mask) is the text for a mask.  Escape hatch for
+ * shared devices: DP_NO_LEVEL_FUSION=1 (no kernel with a grid barrier is used). */
+#define DP_DEVERR_BARRIER 1
+#define DP_DEVERR_NONFINITE_GRAD 2
+int dp_device_error(int clear);
+const char* dp_device_error_describe(int mask);
 
 /* ------------------------------------------------------------------ generic contraction
  * C[b] = act(alpha * op(A[b]) op(B[b]) + beta * C[b] + bias), fp32 MFMA (exact f32).
@@ -264,7 +283,9 @@ typedef struct {
                                         (their gradients are reduced from per-graph slabs); the
                                         pred_model / Set2Set parameters follow */
     int bn_world;                    /* 0 / 1: apply_bn over the local batch; W > 1: over the W equal shards of a
-                                        data-parallel batch (every rank passes the same B) through `exchange` */
+                                        data-parallel batch (every rank passes the same B) through `exchange`.
+                                        bn_world == 1 WITH `exchange` set runs the sync-BN launch sequence and every
+                                        callback over one rank (a one-GPU rehearsal of the collective path) */
     dp_exchange_fn exchange;
     void* exchange_user;
 } dp_encoder_cfg;

@@ -73,6 +73,19 @@ def test_version_and_error_string(lib):
     assert lib.dp_sizeof_encoder_cfg() == C.sizeof(_lib.EncoderCfg)
 
 
+def test_device_error_word_decode(lib):
+    """diffpool_hip.h "Device-side failures": the text for every mask of the per-device error word, and a quiet read on
+    a host without a GPU (no word can be set up: reads as 0, never crashes)."""
+    assert lib.dp_device_error(0) == 0 and lib.dp_device_error(1) == 0
+    none, bar = lib.dp_device_error_describe(0), lib.dp_device_error_describe(_lib.DEVERR_BARRIER)
+    nonf, both = lib.dp_device_error_describe(_lib.DEVERR_NONFINITE_GRAD), lib.dp_device_error_describe(3)
+    assert none == b"no device error"
+    assert b"grid barrier gave up" in bar and b"DP_NO_LEVEL_FUSION" in bar and b"non-finite" not in bar
+    assert b"non-finite gradient norm" in nonf and b"skipped the update" in nonf and b"barrier" not in nonf
+    assert b"grid barrier gave up" in both and b"non-finite" in both
+    assert b"unknown" in lib.dp_device_error_describe(64)
+
+
 def test_argument_errors_are_reported_before_any_launch(lib):
     # NULL pointers / bad dims must come back as DP_ERR_INVALID_ARG with a message (no GPU needed)
     rc = lib.dp_bgemm_f32(None, None, None, None, 1, 4, 4, 4, 4, 4, 4, 0, 0, 0, 0, 0, 1.0, 0.0, 0, None)

@@ -166,3 +166,45 @@ def test_forward_is_bit_reproducible_with_split_k_pooling():
             first = (y, s)
         else:
             assert torch.equal(y, first[0]) and torch.equal(s, first[1]), f"run {i} differs from run 0"
+
+
+def test_grid_barrier_give_up_is_reported_not_silent():
+    """The whole-level kernels' grid barrier (dp_small.hip) rests on co-residency of one workgroup per graph.  When that
+    assumption breaks the bounded spin gives up; this forces the give-up path with the test-only knob
+    DP_TEST_BARRIER_FAIL (read once per process, hence the child process) and checks that it surfaces as an error
+    through the C ABI and that the fused optimizer leaves the parameters alone — tests/_barrier_fail_worker.py."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DP_TEST_BARRIER_FAIL="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_barrier_fail_worker.py")], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    assert "barrier give-up path complete" in r.stdout, r.stdout
+
+
+def test_fused_optimizer_skips_a_non_finite_gradient_and_reports_it():
+    from graph_pooling_amd import _lib
+    from graph_pooling_amd.optim import FusedClipAdam
+    lib = _lib.load()
+    torch.manual_seed(0)
+    model = SoftPoolingGcnEncoder(16, 3, 8, 8, 2, 3, 8, assign_ratio=0.25, linkpred=False).cuda()
+    model._ensure_flat(torch.device("cuda", 0))
+    before = model._flat.detach().clone()
+    opt = FusedClipAdam(model, lr=1e-2, clip=2.0)
+    for p in model.parameters():
+        p.grad = torch.ones_like(p)
+    next(model.parameters()).grad[0, 0] = float("nan")
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(model._flat, before)
+    assert lib.dp_device_error(0) == _lib.DEVERR_NONFINITE_GRAD
+    with pytest.raises(RuntimeError, match="non-finite gradient norm"):
+        opt.step()                                       # the NEXT entry reports it (and clears the word)
+    assert lib.dp_device_error(0) == 0
+    for p in model.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()                                           # a finite step goes through again
+    torch.cuda.synchronize()
+    assert not torch.equal(model._flat, before) and torch.isfinite(model._flat).all()

@@ -49,25 +49,52 @@ def test_softpool_against_reference_golden(name, golden):
     if linkpred:
         close(model.link_loss, a["link_loss"], 1e-5, 1e-6)
     loss.backward()
-    try:
-        grads_close(model, grads)
-    except AssertionError:
-        # Not within rtol 1e-3 of the reference's fp32 numbers.  Two legitimate reasons exist (tests/parity.py): a
-        # max-readout tie resolved differently, or an ill-conditioned entry (a bias gradient in front of a BatchNorm is
-        # a sum that nearly cancels: torch-CPU on another host already moves it by 3e-3).  Either way the claim that
-        # matters is checked against an fp64 run of the oracle with the HIP winners forced: the HIP gradient must be
-        # no further from it than 4x the reference's own fp32 gradient is.
+    # Strict: every gradient tensor within rtol 1e-3 (floor 2e-5 x its largest entry) of the REFERENCE's own fp32 numbers.
+    # The only tensors excused from that are listed, per fixture, in ANCHORED_GRADS: ill-conditioned entries (a bias
+    # gradient in front of a BatchNorm is a sum that nearly cancels — torch-CPU on another host already moves G4's
+    # conv_block2.0.bias by 3e-3 relative) — and those must instead be no further from an fp64 run of the oracle (HIP
+    # winners forced) than 4x the reference's own fp32 gradient is.  Any OTHER tensor that misses the strict tolerance
+    # fails the test, so a regression cannot hide behind the anchored criterion.
+    strict_fail = {}
+    named = dict(model.named_parameters())
+    assert set(named) == set(grads)
+    for k, p in named.items():
+        try:
+            grads_close(_One(k, p), {k: grads[k]})
+        except AssertionError as e:
+            strict_fail[k] = str(e)
+    allowed = ANCHORED_GRADS.get(name, set())
+    extra = set(strict_fail) - allowed
+    assert not extra, f"{name}: tensors outside the allow-list miss rtol 1e-3: " + "; ".join(strict_fail[k] for k in extra)
+    if strict_fail:
+        print(f"[anchored] {name}: {sorted(strict_fail)} checked against the fp64 oracle instead of rtol 1e-3")
         Pm = {k: v.clone().double().requires_grad_(True) for k, v in params.items()}
         yo, inter = O.softpool_forward(Pm, x.double(), adj.double(), a["num_nodes"], x.double(), winners=win)
         lo, _ = O.softpool_loss(yo, T(a["label"]), inter["assign_0"], adj.double(), a["num_nodes"], linkpred)
         lo.backward()
         close(yo, a["ypred"])                              # the forced winners hold the maximum: same forward
-        for k, p in model.named_parameters():
+        for k in strict_fail:
             g64 = Pm[k].grad
-            e_gpu = float((p.grad.detach().cpu().double() - g64).abs().max())
+            e_gpu = float((named[k].grad.detach().cpu().double() - g64).abs().max())
             e_ref = float((grads[k].double() - g64).abs().max())
             assert e_gpu <= 4 * e_ref + 3e-7 * float(g64.abs().max()), \
                 f"{k}: |hip - fp64| {e_gpu:.3e} against the reference's own |fp32 - fp64| {e_ref:.3e}"
+
+
+# gradient tensors of the golden fixtures that may be checked against the fp64 oracle instead of rtol 1e-3 (see above)
+ANCHORED_GRADS = {
+    "g4_softpool_n16_f3": {"conv_block2.0.bias"},
+}
+
+
+class _One:
+    """grads_close() on a single named parameter."""
+
+    def __init__(self, k, p):
+        self._kp = (k, p)
+
+    def named_parameters(self):
+        return [self._kp]
 
 
 @pytest.mark.parametrize("tag", ["concat", "addself", "nobn"])
@@ -546,3 +573,54 @@ def test_step_is_capturable_in_a_hip_graph_and_replays_bit_identically():
                 close(grads_g[k], p.grad, 1e-5, 1e-7)
             else:
                 close(grads_g[k], p.grad, 0, 0)
+
+
+@pytest.mark.parametrize("linkpred", [False, True])
+def test_loss_backward_fast_path_equals_every_other_way_of_calling_it(linkpred):
+    """`model.loss(...).backward()` takes a fast path (no seed fill, no cross-entropy backward launch: encoders._Loss).
+    The same gradients must come out of every other way a caller can start the backward pass — a derived root,
+    an explicit `gradient=`, `torch.autograd.grad` — and an explicit gradient of 2 must double them."""
+    B, N, F_, H, Cc = 5, 40, 4, 8, 3
+    x, adj, nn_, label = O.make_batch(B, N, F_, n_min=5, p=0.15, seed=11, n_classes=Cc)
+    model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, 3, H, assign_ratio=0.25, linkpred=linkpred)
+    params = O.init_params({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=2, bias_scale=0.1)
+    model.load_state_dict(params)
+    model = model.cuda()
+    xd, ad, ld = x.cuda(), adj.cuda(), label.cuda()
+
+    def loss_of():
+        model.zero_grad(set_to_none=True)
+        y = model(xd, ad, nn_, assign_x=xd)
+        return model.loss(y, ld, ad, nn_) if linkpred else model.loss(y, ld)
+
+    def grads_after(run):
+        loss = loss_of()
+        out = run(loss)
+        torch.cuda.synchronize()
+        return out if out is not None else {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    fast = grads_after(lambda l: l.backward())
+    assert type(loss_of()).__name__ == "_Loss"
+    names = [k for k, _ in model.named_parameters()]
+    ways = {
+        "(loss * 1).backward()": lambda l: (l * 1).backward(),
+        "loss.backward(gradient=ones)": lambda l: l.backward(gradient=torch.ones((), device="cuda")),
+        "autograd.grad": lambda l: dict(zip(names, torch.autograd.grad(l, list(model.parameters())))),
+        "loss.sum().backward()": lambda l: l.sum().backward(),
+    }
+    for what, run in ways.items():
+        g = grads_after(run)
+        for k in names:
+            tol = (1e-4, 1e-6 * max(1.0, float(fast[k].abs().max()))) if k.endswith("bias") else (1e-5, 1e-8)
+            try:
+                close(g[k], fast[k], *tol)           # float atomics in bias sums: last-place differences only
+            except AssertionError as e:
+                raise AssertionError(f"{what}: {k}: {e}") from None
+    twice = grads_after(lambda l: l.backward(gradient=torch.full((), 2.0, device="cuda")))
+    for k in names:
+        close(twice[k], 2 * fast[k], 1e-4, 1e-6 * max(1.0, float(fast[k].abs().max())))
+    # and the oracle agrees with the fast path
+    win = gpu_winners(model, 2)
+    _, _, _, go = _oracle_run(params, x, adj, nn_, label, linkpred, winners=win)
+    loss_of().backward()
+    grads_close(model, go)

@@ -529,3 +529,99 @@ def test_mean_aggregator_golden(lib, golden):
     neighs = [a["indices"][a["indptr"][i]:a["indptr"][i + 1]].tolist() for i in range(len(a["indptr"]) - 1)]
     (O.mean_aggregate(to, a["nodes"].tolist(), neighs) * g).sum().backward()
     close(table.grad, to.grad, 1e-4, 1e-6)
+
+
+def _g8_sets(a):
+    return [set(a["indices"][a["indptr"][i]:a["indptr"][i + 1]].tolist()) for i in range(len(a["indptr"]) - 1)]
+
+
+def test_mean_aggregator_module_against_reference_golden(golden):
+    """MeanAggregator.forward itself (aggregators.py:30-63, num_sample=None): host neighbour SETS -> CSR, the `features`
+    callable looked up with a LongTensor of the unique nodes on the device, then the gather kernel — against G8, which
+    the reference's own class produced; gradient through the embedding table against the oracle."""
+    a, _, _ = golden("g8_mean_aggregator")
+    from graph_pooling_amd.aggregators import MeanAggregator
+    emb = torch.nn.Embedding(a["table"].shape[0], a["table"].shape[1]).cuda()
+    with torch.no_grad():
+        emb.weight.copy_(torch.from_numpy(a["table"]))
+    seen = []
+
+    def features(ids):
+        assert ids.dtype == torch.int64 and ids.is_cuda
+        seen.append(ids)
+        return emb(ids)
+    agg = MeanAggregator(features, cuda=True, gcn=False)
+    out = agg(a["nodes"].tolist(), _g8_sets(a), num_sample=None)
+    close(out, torch.from_numpy(a["out"]), 1e-5, 1e-6)
+    assert len(seen) == 1 and len(set(seen[0].tolist())) == seen[0].numel()      # one lookup, unique nodes only
+    g = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
+    (out * g.cuda()).sum().backward()
+    to = torch.from_numpy(a["table"]).requires_grad_(True)
+    (O.mean_aggregate(to, a["nodes"].tolist(), [sorted(s) for s in _g8_sets(a)]) * g).sum().backward()
+    close(emb.weight.grad, to.grad, 1e-4, 1e-6)
+
+
+def test_mean_aggregator_module_gcn_PARITY_UNPINNED(golden):
+    """gcn=True (the node itself joins its neighbour set): the reference's line raises (`set + set`, aggregators.py:47,
+    SURVEY Appendix B D10), so this is pinned to the oracle's restatement of the intended semantics only."""
+    a, _, _ = golden("g8_mean_aggregator")
+    from graph_pooling_amd.aggregators import MeanAggregator
+    table = torch.from_numpy(a["table"]).cuda()
+    agg = MeanAggregator(lambda ids: table[ids], cuda=True, gcn=True)
+    nodes = a["nodes"].tolist()
+    out = agg(nodes, _g8_sets(a), num_sample=None)
+    ref = O.mean_aggregate(torch.from_numpy(a["table"]), nodes, [sorted(s) for s in _g8_sets(a)], gcn=True)
+    close(out, ref, 1e-5, 1e-6)
+    assert float((out.cpu() - torch.from_numpy(a["out"])).abs().max()) > 1e-3       # and it differs from gcn=False
+
+
+def test_mean_aggregator_module_sampling_matches_the_oracle_on_the_same_samples(golden):
+    """num_sample=3 (aggregators.py:38-42): sets with >= 3 neighbours are sub-sampled with `random.sample`.  The
+    reference's draw is unseeded, so the check replays the module's draws: same `random.seed`, same call order, and
+    the oracle is fed the sampled sets."""
+    import random
+    a, _, _ = golden("g8_mean_aggregator")
+    from graph_pooling_amd.aggregators import MeanAggregator
+    table = torch.from_numpy(a["table"]).cuda()
+    agg = MeanAggregator(lambda ids: table[ids], cuda=True, gcn=False)
+    nodes, sets = a["nodes"].tolist(), _g8_sets(a)
+    random.seed(1234)
+    out = agg(nodes, sets, num_sample=3)
+    random.seed(1234)
+    sampled = [sorted(random.sample(sorted(s), 3)) if len(s) >= 3 else sorted(s) for s in sets]
+    assert all(len(s) <= 3 for s in sampled) and any(len(s) < len(t) for s, t in zip(sampled, sets))
+    close(out, O.mean_aggregate(torch.from_numpy(a["table"]), nodes, sampled), 1e-5, 1e-6)
+
+
+def test_supervised_graphsage_head_on_a_stub_encoder():
+    """graphsage.py:7-26 with the D10 repairs: scores = enc(nodes) @ weight (the library's GEMM), cross-entropy on the
+    raw scores; gradients reach the head's weight and the encoder."""
+    from graph_pooling_amd.graphsage import SupervisedGraphSage
+
+    class Enc(torch.nn.Module):
+        embed_dim = 5
+
+        def __init__(self):
+            super().__init__()
+            self.table = torch.nn.Parameter(torch.randn(11, 5))
+
+        def forward(self, nodes):
+            return self.table[torch.as_tensor(nodes, device=self.table.device)]
+
+    torch.manual_seed(0)
+    head = SupervisedGraphSage(3, Enc()).cuda()
+    nodes, labels = [0, 4, 7, 10], torch.tensor([[0], [2], [1], [2]]).cuda()
+    scores = head(nodes)
+    assert tuple(scores.shape) == (4, 3)
+    t, w = head.enc.table.detach().cpu().requires_grad_(True), head.weight.detach().cpu().requires_grad_(True)
+    ref_scores = t[torch.tensor(nodes)] @ w
+    close(scores, ref_scores, 1e-5, 1e-6)
+    ref = torch.nn.functional.cross_entropy(ref_scores, labels.cpu().squeeze())
+    loss = head.loss(nodes, labels)
+    close(loss, ref, 1e-5, 1e-6)
+    loss.backward()
+    ref.backward()
+    close(head.weight.grad, w.grad, 1e-4, 1e-6)
+    close(head.enc.table.grad, t.grad, 1e-4, 1e-6)
+    with pytest.raises(RuntimeError, match="GPU"):          # a CPU encoder output is refused, not computed
+        SupervisedGraphSage(3, Enc())([0, 1])

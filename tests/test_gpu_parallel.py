@@ -1,6 +1,12 @@
-"""Data parallelism with the HIP kernels in the loop: two ranks share the box's one GPU and talk over gloo (RCCL
-refuses two ranks on one device; the collective code path is the same torch.distributed API).  Sync-BN mode must
-reproduce ONE reference step on the concatenated batch (SURVEY §8(e) mode ii, encoders.py:1048-1052, 1326-1331)."""
+"""Data parallelism with the HIP kernels in the loop.
+
+Two ranks share the box's one GPU and talk over gloo (RCCL refuses two ranks on one device; the collective code path is
+the same torch.distributed API): sync-BN mode must reproduce ONE reference step on the concatenated batch (SURVEY §8(e)
+mode ii, encoders.py:1048-1052, 1326-1331) and the default local-BN mode the mean of the per-shard reference steps
+(mode i) — both also at BASELINE configs[3]'s shard shape (B = 20 per rank, N = 500, F = 89).
+
+The RCCL backend itself runs with ONE rank (tests/_rccl_world1_worker.py): AVG all-reduce, the sync-BN all-gathers
+through the library's callback, and a whole step with its collectives captured into a hipGraph."""
 import os
 import socket
 import subprocess
@@ -20,11 +26,28 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("case", ["small", "packed"])
+def test_rccl_world1_collectives_and_captured_step():
+    """One rank on the real `nccl` (= RCCL) backend, in a fresh child process, once (no retry): see the worker."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_world1_worker.py")], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-6000:]
+    assert "RCCL world-1 run complete" in r.stdout, r.stdout
+
+
+def test_local_bn_two_ranks_at_the_dd_shard_shape_match_the_mean_of_per_shard_oracle_steps():
+    _two_ranks("dd_local", "equals the mean of the per-shard oracle steps")
+
+
+@pytest.mark.parametrize("case", ["small", "packed", "dd"])
 def test_sync_bn_two_ranks_match_the_oracle_on_the_concatenated_batch(case):
+    _two_ranks(case, "equals the oracle on the concatenated batch")
+
+
+def _two_ranks(case, expect):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sync_bn_worker.py"), case]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-6000:]
-    assert r.stdout.count("equals the oracle on the concatenated batch") == 2, r.stdout
+    assert r.stdout.count(expect) == 2, r.stdout

@@ -126,13 +126,7 @@ def test_supervised_graphsage_head_on_a_stub_encoder():
     torch.manual_seed(0)
     head = SupervisedGraphSage(3, Enc())
     assert tuple(head.weight.shape) == (5, 3) and set(dict(head.named_parameters())) == {"weight", "enc.table"}
-    nodes, labels = [0, 4, 7, 10], torch.tensor([[0], [2], [1], [2]])
-    scores = head(nodes)
-    assert tuple(scores.shape) == (4, 3)
-    ref = torch.nn.functional.cross_entropy(head.enc(nodes) @ head.weight, labels.squeeze())
-    loss = head.loss(nodes, labels)
-    assert torch.allclose(loss, ref)
-    loss.backward()
-    assert head.weight.grad is not None and head.enc.table.grad is not None
+    with pytest.raises(RuntimeError, match="GPU"):          # no CPU path (numerics: tests/test_gpu_ops.py)
+        head([0, 4, 7, 10])
     with pytest.raises(ValueError):
         SupervisedGraphSage(0, Enc())
