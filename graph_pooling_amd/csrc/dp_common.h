@@ -394,6 +394,9 @@ struct HeadArgs {
     float* hid[DP_MAX_PRED + 2];   // hid[0] = features [B, dims[0]], hid[i] = post-ReLU activations, hid[n_pred] = ypred
     int B;
     long long* labels;             // optional: arg-max class per graph (evaluation)
+    const int* poison[DP_MAX_LEVELS + 1];   // device error words of this forward's grid barriers (n_poison of them):
+    int n_poison;                           // any non-zero -> ypred = NaN.  Max readouts and ReLUs swallow NaN, so the
+                                            // poisoned BatchNorm statistics alone may not reach ypred
 };
 struct HeadBwdArgs {
     HeadArgs h;              // dims / offsets / saved activations (hid[] read-only here)

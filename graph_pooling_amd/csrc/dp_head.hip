@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
     float* cur = h0;
     float* nxt = h1;
     int wo = 0, bo = 0;
+    bool poisoned = false;
+    for (int i = 0; i < a.n_poison; ++i)
+        poisoned |= __hip_atomic_load(a.poison[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     for (int i = 0; i < a.n_pred; ++i) {
         const int din = a.dims[i], dout = a.dims[i + 1];
         const bool last = i == a.n_pred - 1;
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
             if (wave == 0 && j < dout) {
                 s = sv[lane] + sv[64 + lane] + sv[128 + lane] + sv[192 + lane] + bl[bo + j];
                 if (!last) s = fmaxf(s, 0.f);
+                else if (poisoned) s = __builtin_nanf("");
                 nxt[j] = s;
                 out[j] = s;
             }

@@ -872,6 +872,8 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
     // grid-barrier tickets of a whole-level kernel: cleared in stream order by the softmax launch of the level below
     // (together with its split-K tickets); a small level 0 has no such launch in front of it and clears its own
     int* level_bar = nullptr;
+    const int* poison[DP_MAX_LEVELS + 1];   // error words of the whole-level kernels' barrier blocks (read by the head launch)
+    int n_poison = 0;
     for (int j = 0; j <= P; ++j) {
         const LevelInfo li = level_info(c, j);
         const LevelSave& lv = sv.lv[j];
@@ -889,6 +891,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
         io.pack = (j == 0 && pack_in_level) ? &pack : nullptr;
         level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part, sc.part_b, j == 0 ? pkp : nullptr, sc.vs,
                       sc.lvl_part, level_bar, sc.part_all);
+        if (level_bar && !q.dry && !bn_sync(c) && level_is_fused(c, li, io, true)) poison[n_poison++] = level_bar + 1;
         level_bar = nullptr;
         const int* nn_j = (j == 0) ? num_nodes : nullptr;
         if (c.readout == 0) {
@@ -950,6 +953,8 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
     }
     // pred_model
     if (fused_head) {
+        for (int i = 0; i < n_poison; ++i) head.poison[i] = poison[i];
+        head.n_poison = n_poison;
         head_fwd(q, head);
         return q.err;
     }

@@ -1020,9 +1020,12 @@ static bool level_kernels_admitted() {
                               reinterpret_cast<const void*>(&k_small_level_bwd)};
         for (const void* fn : fns) {
             int blocks = 0;
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess ||
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 1024, 150 * 1024) != hipSuccess || blocks < 1) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 1024, 150 * 1024);
+            if (e != hipSuccess || blocks < 1) {
                 (void)hipGetLastError();
+                set_error("whole-level kernels disabled: the runtime admits %d resident 1024-thread workgroups with 150 KiB "
+                          "of LDS per CU (%s)", blocks, hipGetErrorString(e));
                 v = -1;
             }
         }

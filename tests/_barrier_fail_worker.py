@@ -2,7 +2,8 @@
 knob DP_TEST_BARRIER_FAIL=1 the whole-level kernels wait for one arrival more than will ever come, with a spin limit of
 64 — the give-up path of dp_small.hip's grid barrier.  What must happen (diffpool_hip.h "Device-side failures"):
 
-  * the step's outputs are NaN (poisoned statistics), never plausible numbers;
+  * the step's outputs are NaN, never plausible numbers (the kernel poisons its BatchNorm statistics, but max readouts
+    and ReLUs swallow NaN — the prediction-head launch therefore reads the barrier's error word and writes NaN logits);
   * the device's error word carries DP_DEVERR_BARRIER once the stream has drained, and the NEXT model-level call
     returns DP_ERR_DEVICE -> RuntimeError naming the grid barrier, before launching anything;
   * the fused optimizer refuses the NaN gradients: parameters bit-identical to before the step."""
@@ -32,7 +33,8 @@ def main():
     before = model._flat.detach().clone()
     ypred = model(xd, ad, nn_, assign_x=xd)            # the pooled level (n = 16) runs k_small_level_fwd
     torch.cuda.synchronize()
-    assert not torch.isfinite(ypred).all(), "a barrier that gave up must poison the outputs"
+    assert not torch.isfinite(ypred).all(), ("a barrier that gave up must poison the outputs; error word "
+                                             f"{lib.dp_device_error(0)}, last message: {lib.dp_last_error_string()!r}")
     assert lib.dp_device_error(0) & _lib.DEVERR_BARRIER, "the give-up did not reach the device error word"
     print("outputs poisoned, error word set", flush=True)
     try:

@@ -6,12 +6,14 @@ collective on over the single rank.  Executes, on the real RCCL backend:
   2. the sync-BN exchange through the library's callback (dist.all_gather_into_tensor) and the link-normaliser
      all-reduce — the step must equal the oracle on the batch (one rank: global statistics == local statistics);
   3. collective_capture_works (a captured + replayed all-reduce on a throw-away communicator);
-  4. a whole step — forward, loss, backward, gradient all-reduce, with the sync-BN all-gathers inside — captured into
-     ONE hipGraph; replay must reproduce the eager step (every tensor except `*.bias`, whose float atomics differ in
-     the last place between any two runs).
+  4. a whole step — forward, loss, backward and the gradient all-reduce — captured into ONE hipGraph; replay must
+     reproduce the eager step (every tensor except `*.bias`, whose float atomics differ in the last place between any
+     two runs).  Mode `local` (argv[1], default): local BatchNorm statistics, the captured collective is the gradient
+     all-reduce — bench.py's N > 1 configuration.  Mode `sync`: sync-BN, the eight all-gathers are captured too.
 
 It is a one-rank run: it proves the calls execute and compose with graph capture on this runtime, not that two ranks
-agree.  Any RCCL failure is printed as `RCCL-ERROR: <text>` and the process exits non-zero; nothing is retried."""
+agree (at one rank RCCL short-cuts an in-place all-reduce to nothing and an all-gather to a device copy).  Any RCCL
+failure is printed as `RCCL-ERROR: <text>` and the process exits non-zero; nothing is retried."""
 import os
 import sys
 import traceback
@@ -25,7 +27,9 @@ sys.path.insert(0, ROOT)
 
 def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", sys.argv[1] if len(sys.argv) > 1 else "29533")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    mode = sys.argv[1] if len(sys.argv) > 1 else "local"
+    sync_bn = mode == "sync"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
     torch.cuda.set_device(0)
@@ -42,7 +46,7 @@ def main():
     params = O.init_params({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=9, bias_scale=0.1)
     model.load_state_dict(params)
     model = model.cuda()
-    dp = DataParallelEncoder(model, sync_bn=True, force=True)
+    dp = DataParallelEncoder(model, sync_bn=sync_bn, force=True)
     assert dp.backend == "nccl" and dp.reduce_op == dist.ReduceOp.AVG
     xd, ad, ld = x.cuda(), adj.cuda(), label.cuda()
     nd = torch.from_numpy(nn_).cuda()             # resident, as bench.py passes it: no H2D copy inside the capture
@@ -58,9 +62,11 @@ def main():
     # ---- 1 + 2: eager step over RCCL, against the oracle
     ypred, loss = step()
     torch.cuda.synchronize()
-    assert model._sync_bn.error is None, model._sync_bn.error
-    n_calls = model._sync_bn.calls
-    assert n_calls == 8, n_calls          # 2 (L - 1) (1 + 2 P) all-gathers at L = 3, P = 1
+    n_calls = 0
+    if sync_bn:
+        assert model._sync_bn.error is None, model._sync_bn.error
+        n_calls = model._sync_bn.calls
+        assert n_calls == 8, n_calls          # 2 (L - 1) (1 + 2 P) all-gathers at L = 3, P = 1
     wins = gpu_winners(model, 2)
     P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     yo, inter = O.softpool_forward(P, x, adj, nn_, x, winners=wins)
@@ -91,11 +97,12 @@ def main():
     model.zero_grad(set_to_none=True)
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
         gy, gl = step()
-    captured_calls = model._sync_bn.calls
+    captured_calls = model._sync_bn.calls if sync_bn else 0
     for _ in range(3):
         g.replay()
     torch.cuda.synchronize()
-    assert model._sync_bn.calls == captured_calls       # replays re-run the captured collectives, not the callback
+    if sync_bn:
+        assert model._sync_bn.calls == captured_calls   # replays re-run the captured collectives, not the callback
     torch.testing.assert_close(gy, eager_y, rtol=0, atol=0)
     torch.testing.assert_close(gl, eager_loss, rtol=0, atol=0)
     for k, p in model.named_parameters():
@@ -103,9 +110,9 @@ def main():
             torch.testing.assert_close(p.grad, eager[k], rtol=1e-4, atol=1e-7)
         else:
             torch.testing.assert_close(p.grad, eager[k], rtol=0, atol=0, msg=lambda m, k=k: f"{k}: {m}")
-    print("captured step with the RCCL collectives inside replays the eager step", flush=True)
+    print(f"captured step ({mode} BatchNorm) with the RCCL collectives inside replays the eager step", flush=True)
     dist.destroy_process_group()
-    print("RCCL world-1 run complete", flush=True)
+    print(f"RCCL world-1 run complete ({mode})", flush=True)
 
 
 if __name__ == "__main__":

@@ -26,13 +26,34 @@ def _free_port():
     return p
 
 
-def test_rccl_world1_collectives_and_captured_step():
-    """One rank on the real `nccl` (= RCCL) backend, in a fresh child process, once (no retry): see the worker."""
+def _rccl_world1(mode):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_world1_worker.py")], cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=420)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_world1_worker.py"), mode], cwd=ROOT,
+                          env=env, capture_output=True, text=True, timeout=420)
+
+
+def test_rccl_world1_collectives_and_captured_step():
+    """One rank on the real `nccl` (= RCCL) backend, in a fresh child process, once (no retry): broadcast, ReduceOp.AVG
+    gradient all-reduce against the oracle, collective_capture_works, and the step with its gradient all-reduce captured
+    into one hipGraph (bench.py's N > 1 configuration) replaying the eager step."""
+    r = _rccl_world1("local")
     assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-6000:]
-    assert "RCCL world-1 run complete" in r.stdout, r.stdout
+    assert "RCCL world-1 run complete (local)" in r.stdout, r.stdout
+
+
+def test_rccl_world1_sync_bn_collectives_eager_and_captured():
+    """The same with sync-BN: the eager step (eight all_gather_into_tensor through the library's callback + the
+    link-normaliser all-reduce, all on RCCL) must equal the oracle.  CAPTURING that step is recorded, not required: at
+    ONE rank RCCL turns an all-gather into a device-to-device copy, and a copy node inside a hipGraph is the known-bad
+    construct of this runtime (memset / memcpy nodes replay garbage or crash at instantiate on ROCm
+    7.2) — round 3 observed a host segfault in exactly this capture.  With two or more ranks the collective is a kernel;
+    that configuration has not run anywhere yet."""
+    r = _rccl_world1("sync")
+    assert "eager RCCL step" in r.stdout and "equals the oracle" in r.stdout, r.stdout[-3000:] + "\n" + r.stderr[-6000:]
+    if r.returncode != 0:
+        pytest.xfail(f"sync-BN all-gathers captured at world size 1: child exited with {r.returncode} "
+                     "(single-rank all-gather = device copy node in the graph)")
+    assert "RCCL world-1 run complete (sync)" in r.stdout, r.stdout
 
 
 def test_local_bn_two_ranks_at_the_dd_shard_shape_match_the_mean_of_per_shard_oracle_steps():
