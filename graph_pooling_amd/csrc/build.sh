@@ -8,7 +8,7 @@ BUILD=build
 if [ "${DP_STAMP:-0}" = "1" ]; then OUT=../libdiffpool_hip_stamp.so; BUILD=build_stamp; EXTRA="-DDP_STAMP"; else EXTRA=""; fi
 # DP_VARIANT=<name> DP_EXTRA_FLAGS="...": an experimental build next to the product (libdiffpool_hip_<name>.so)
 if [ -n "${DP_VARIANT:-}" ]; then OUT=../libdiffpool_hip_${DP_VARIANT}.so; BUILD=build_${DP_VARIANT}; EXTRA="$EXTRA ${DP_EXTRA_FLAGS:-}"; fi
-SRCS="dp_api.hip dp_gemm.hip dp_gemm_split.hip dp_rowops.hip dp_linkpred.hip dp_model.hip dp_set2set.hip dp_meanagg.hip dp_agg.hip dp_small.hip dp_head.hip dp_optim.hip dp_batch.hip"
+SRCS="dp_api.hip dp_gemm.hip dp_gemm_split.hip dp_rowops.hip dp_linkpred.hip dp_model.hip dp_set2set.hip dp_meanagg.hip dp_agg.hip dp_small.hip dp_level0.hip dp_head.hip dp_optim.hip dp_batch.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fvisibility=hidden $EXTRA"
 mkdir -p $BUILD
 pids=()

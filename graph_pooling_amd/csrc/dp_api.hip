@@ -45,6 +45,7 @@ const Knobs& knobs() {
         k.no_rowpart_hook = getenv("DP_NO_ROWPART_HOOK") != nullptr;
         k.no_row_quads = getenv("DP_NO_ROW_QUADS") != nullptr;
         k.test_barrier_fail = getenv("DP_TEST_BARRIER_FAIL") != nullptr;
+        k.no_l0_persist = getenv("DP_NO_L0_PERSIST") != nullptr;
     });
     return k;
 }

@@ -152,6 +152,7 @@ struct Knobs {
     bool no_rowpart_hook;  // DP_NO_ROWPART_HOOK: BatchNorm-backward partials in a launch of their own
     bool no_widen_fusion;  // DP_NO_WIDEN_FUSION: widening layers' row-local products on the GEMM kernels
     bool no_agg_first;     // DP_NO_AGG_FIRST: every GraphConv as A (x W), also the layers that widen a lot
+    bool no_l0_persist;    // DP_NO_L0_PERSIST: level 0 as the launch sequence of rounds 1-2 instead of the persistent kernel
     bool test_barrier_fail;  // DP_TEST_BARRIER_FAIL: TEST ONLY — grid barriers wait for one arrival too many with a
                              // tiny spin limit, so the give-up path runs (tests/test_gpu_edge_cases.py)
 };
@@ -380,6 +381,62 @@ size_t small_level_part_floats(int B, int n, int L);
 void small_level_fwd(Seq& q, const SmallLevelIO& io, int B, int n, const int* dims, int L, int add_self, int bn);
 void small_level_bwd(Seq& q, const SmallLevelIO& io, const float* dZe, float* dX0, float* dadj, float* slabs,
                      long slab_stride, int B, int n, const int* dims, int L, int add_self, int bn);
+
+// (dp_level0.hip) the whole level-0 forward — adjacency pack, every GraphConv layer of the embed + assign stacks with
+// BatchNorm, max readout, assign head + softmax, T = A^T S, X' = S^T Z, A' = T^T S — as ONE persistent launch: a
+// workgroup per (graph, block of RB rows) keeps its rows of the bf16 adjacency in LDS across all passes; what crosses
+// workgroups (the split operand of each aggregation, BatchNorm partials, the pooled partial products) travels through
+// global memory behind per-graph / grid-wide barriers.
+struct L0Stack {
+    int dims[DP_MAX_LAYERS + 1];
+    long w_off[DP_MAX_LAYERS], b_off[DP_MAX_LAYERS];
+};
+struct Level0Fwd {
+    int B, N, L, G;                // G = 2: embed + assign stacks (a pooling level follows); 1: embed only
+    int bn, train, do_max, mask_readout;
+    const float* A;                // [B, N, N] fp32 as delivered
+    const float* x0[2];            // per stack: [B, N, st[g].dims[0]] contiguous
+    const int* num_nodes;          // int32[B] or null
+    const float* params;
+    L0Stack st[2];
+    float* Y[DP_MAX_LAYERS];       // non-last layers: joint normalised pre-ReLU output [B, N, ctot[l]]
+    float* invn[DP_MAX_LAYERS];    // [B, N, G]
+    float* stats[DP_MAX_LAYERS];   // [N, G, 2] (mu, rstd) of the non-last layers
+    float* Z[2];                   // concat buffers Ze [B, N, ldz[0]], Za [B, N, ldz[1]]
+    int ldz[2];
+    int coff[2][DP_MAX_LAYERS];    // column of layer l's slice in Z[g]
+    // pooling (G == 2)
+    int K;
+    long wp_off, bp_off;           // assign_pred Linear [K, Da], [K] (bp_off may be -1)
+    float* S;                      // [B, N, K]
+    float* S2;                     // caller-visible copy or null
+    float* Tt;                     // [B, N, K] = A^T S
+    float* Xn;                     // [B, K, D]
+    float* An;                     // [B, K, K]
+    // max readout (do_max)
+    float* feat;                   // [B, ldfeat], this level's slice at featoff
+    int ldfeat, featoff, rw, zoff; // readout width, first Ze column it covers
+    int* argmax;                   // [B, rw]
+    // packed adjacency for the backward pass
+    unsigned short *pkA, *pkAt;
+    int pk_ld;
+    int* pk_flag;                  // 256-byte block: word 0 = "some entry is not bf16-exact", rest zero
+    // exchange scratch (workspace)
+    unsigned short* vs;            // 3-plane split of the current aggregation operand
+    float* part;                   // [B, N, G, 2]
+    float* xpart;                  // [B, T, epad] partial X' | A'
+    float* mpart;                  // [B, T, rw, 2] partial (max, row)
+    int* bar;                      // level0_bar_ints(B) ints, zero on first use, self-cleaning afterwards
+    int* next_bar;                 // 64 ints cleared for the launch that follows (pooled level's grid barrier), or null
+    void* zero_p;                  // side job: clear this region (the backward accumulators), 16-byte aligned
+    size_t zero_bytes;
+};
+bool level0_persistent_ok(const Level0Fwd& a);
+size_t level0_bar_ints(int B);
+size_t level0_xpart_floats(const Level0Fwd& a);
+size_t level0_mpart_floats(const Level0Fwd& a);
+const int* level0_error_word(const int* bar);        // device word the head launch checks (ypred = NaN when set)
+void level0_forward(Seq& q, const Level0Fwd& a);
 
 // (dp_head.hip) last-level max readout + pred_model in one launch per direction
 struct HeadArgs {

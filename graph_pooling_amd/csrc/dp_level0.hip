@@ -1,0 +1,1053 @@
+// Level 0 of the DiffPool forward as ONE persistent launch (round 3).
+//
+//   gcn_forward of the embed + assign stacks          encoders.py:1054-1081, 1254, 1269   (GraphConv :962-974, apply_bn :1048-1052)
+//   max readout of the embedding                      encoders.py:1257
+//   S = softmax(Linear(Za)) * mask                    encoders.py:1273-1275
+//   X' = S^T Z,  A' = S^T A S  (as Tt = A^T S, A' = Tt^T S)                               encoders.py:1278-1279
+//
+// Rounds 1-2 ran this as 11 dependent launches (111 us of the 344 us DD step): every kernel a ~4 us floor plus cold
+// memory round trips, every adjacency pass re-reading its panel.  Here a workgroup owns RB rows of ONE graph for the
+// whole level: it converts its rows of the fp32 adjacency to bf16 ONCE into LDS (and writes the packed A / A^T copies
+// the backward pass reads), and keeps them there for every GraphConv pass; row-local work (the x W transforms, bias,
+// l2-normalise, ReLU, BatchNorm apply, the assign head, softmax, mask) never leaves the workgroup.
+//
+// What crosses workgroups goes through global memory behind barriers of this launch:
+//   * the operand of an aggregation U = A_rows . P needs ALL rows of P of the graph: each workgroup writes the exact
+//     3-plane bf16 split of its rows (the layout dp_agg.hip reads), then a PER-GRAPH barrier (T arrivals);
+//   * apply_bn couples all graphs (statistics per node index over batch x features): row partials (mean, M2), then a
+//     GRID barrier (per-graph counters feeding one global counter);
+//   * X' = S^T Z and A' = Tt^T S contract over the node index: per-workgroup partial tiles, a per-graph barrier, then
+//     the graph's workgroups sum disjoint slices in block order (deterministic); the max readout likewise.
+// Barriers are sense-reversing (count + generation, never reset by the host; the last workgroup to FINISH the launch
+// clears every count, so a launch that timed out leaves a clean block too), bounded (a wait that gives up raises
+// DP_DEVERR_BARRIER and a device word the prediction head turns into NaN logits), and need every workgroup resident:
+// the launcher only takes this path when B * T <= CUs with one 512-thread workgroup per CU.
+//
+// Memory model (MI355X: per-XCD L2s are not coherent, a CU's L1 is never refreshed by another CU's stores): every byte
+// another workgroup of the launch reads is stored write-through (`sc1`) and loaded `sc1` (raw buffer builtins, aux 16);
+// every storing wave drains vmcnt before the workgroup barrier that precedes its arrival (cdna guide, Guideline 16 R1).
+//
+// Exactness: as dp_agg.hip — a bf16-exact adjacency (0/1 graphs) is multiplied as bf16 x (hi + mid + lo) planes on the
+// bf16 MFMA with fp32 accumulation, every product exact; a graph whose adjacency is NOT bf16-exact takes an fp32 MFMA
+// loop that reads the fp32 adjacency from global memory (correct, slow; decided per graph on the device).
+#include "dp_common.h"
+
+namespace dp {
+
+#ifdef DP_STAMP
+// diagnostic build only (csrc/build.sh DP_STAMP=1, tools/l0_stamps.py): shader-clock stamps of three workgroups
+__device__ unsigned long long g_l0_stamps[3][64];
+#define L0_STAMP(i)                                                                                    \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && (wid == 0 || wid == (int)gridDim.x / 2 || wid == (int)gridDim.x - 1)) \
+            g_l0_stamps[wid == 0 ? 0 : (wid == (int)gridDim.x - 1 ? 2 : 1)][i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define L0_STAMP(i) \
+    do {            \
+    } while (0)
+#endif
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int L0_NT = 512;            // threads per workgroup
+constexpr int L0_NW = 8;              // waves: (k quarter) x (column half) in the aggregations
+constexpr int L0_TEAMS = L0_NT / 16;
+constexpr int L0_NK = 4;              // a 16-lane team holds a row group of <= 64 columns in 4 registers per lane
+constexpr int L0_BPAIRS = 4;          // BatchNorm combine: <= 64 graphs (4 partial pairs per lane)
+constexpr float L0_L2_EPS = 1e-12f;
+constexpr float L0_BN_EPS = 1e-5f;
+constexpr int L0_SPIN_LIMIT = 1 << 22;
+
+// barrier block (ints; every word that is polled or added to sits on a 64-byte line of its own)
+constexpr int BAR_GCOUNT = 0, BAR_GGEN = 16, BAR_DONE = 32, BAR_GFLAG = 48, BAR_ERR = 64, BAR_GRAPH0 = 128;
+constexpr int BAR_GSTRIDE = 48;       // per graph: +0 count, +16 generation, +32 "adjacency not bf16-exact"
+
+// ---- write-through / L1-bypassing access to what other workgroups of this launch write or read
+struct ScBuf {
+    __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ ScBuf sc_buf(const void* p, size_t bytes) {
+    return ScBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)};
+}
+__device__ __forceinline__ u32x4 sc_ld16(ScBuf b, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 16); }
+__device__ __forceinline__ void sc_st16(ScBuf b, unsigned off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, b.r, off, 0, 16); }
+__device__ __forceinline__ float sc_ldf(ScBuf b, unsigned off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.r, off, 0, 16));
+}
+__device__ __forceinline__ void sc_stf(ScBuf b, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b.r, off, 0, 16);
+}
+__device__ __forceinline__ int ag_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ag_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ag_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct L0Args {
+    Level0Fwd f;
+    int T, RB;                     // row blocks per graph, rows per block (16 * MI)
+    int ldp;                       // bf16 elements per LDS adjacency row (8 mod 128)
+    int K8;                        // k8 groups of the split operand: ceil(N / 32) * 4
+    int steps;                     // 32-deep k-steps: ceil(N / 32)
+    int epad;                      // K*D + K*K padded to a multiple of 4
+    int lds_act[2];                // float offsets of the activation rows [RB][ldz[g]] in LDS
+    int lds_scr;                   // float offset of the scratch region
+    int scr_floats;
+    int* dev_err;
+    int spin_limit, target_bias;
+    long zero_n16;
+};
+
+// C[M x N] = op(A)[M x K] . op(B)[K x N], both operands in LDS, fp32 MFMA 16x16x4, tiles dealt to the waves round
+// robin (dp_small.hip lds_mma2: running fragment pointers, only the partial k-step is masked).  Rows / columns past
+// M / N are clamped duplicates whose results nobody stores.
+template <bool TA, bool TB, typename Store>
+__device__ inline void l0_mma(const float* A, int lda, const float* B, int ldb, int M, int N, int K, Store store,
+                              int wave_shift = 0) {
+    const int lane = threadIdx.x & 63;
+    const int wave = ((threadIdx.x >> 6) + L0_NW - wave_shift % L0_NW) % L0_NW;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int tm = (M + 15) / 16, tn = (N + 15) / 16;
+    const int sa4 = 4 * (TA ? lda : 1), sb4 = 4 * (TB ? 1 : ldb);
+    for (int t = wave; t < tm * tn; t += L0_NW) {
+        const int tr = t / tn, tc = t - tr * tn;
+        const int i = tr * 16 + l15, j = tc * 16 + l15;
+        const float* ap = (TA ? A + min(i, M - 1) : A + min(i, M - 1) * lda) + kq * (sa4 >> 2);
+        const float* bp = (TB ? B + min(j, N - 1) * ldb : B + min(j, N - 1)) + kq * (sb4 >> 2);
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        int k = 0;
+        for (; k + 16 <= K; k += 16) {
+            const float a0 = ap[0], a1 = ap[sa4], a2 = ap[2 * sa4], a3 = ap[3 * sa4];
+            const float b0 = bp[0], b1 = bp[sb4], b2 = bp[2 * sb4], b3 = bp[3 * sb4];
+            ap += 4 * sa4;
+            bp += 4 * sb4;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc1, 0, 0, 0);
+        }
+        for (; k + 4 <= K; k += 4) {
+            const float a0 = ap[0], b0 = bp[0];
+            ap += sa4;
+            bp += sb4;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+        }
+        if (k < K) {
+            const bool kin = k + kq < K;
+            const float a0 = kin ? ap[0] : 0.f, b0 = kin ? bp[0] : 0.f;      // (reads past K stay inside the LDS region)
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = tr * 16 + kq * 4 + r;
+            if (row < M && j < N) store(row, j, acc0[r] + acc1[r]);
+        }
+    }
+}
+
+// ---- barriers.  Every thread calls; returns false once a wait of this workgroup has given up (sticky).
+template <bool GRID>
+__device__ inline bool l0_barrier(const L0Args& a, int b, int* sflag /*LDS: [0] ok, [1] failed (sticky)*/) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = sflag[1] ? 0 : 1;
+        int* gc = a.f.bar + BAR_GRAPH0 + b * BAR_GSTRIDE;
+        int* pollw = GRID ? a.f.bar + BAR_GGEN : gc + 16;
+        const int my_gen = ag_ld(pollw);                   // read BEFORE arriving
+        const int old = ag_add(gc, 1);
+        bool released = false;
+        if (old == a.T - 1 + a.target_bias) {              // last of this graph
+            ag_st(gc, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (GRID) {
+                const int o2 = ag_add(a.f.bar + BAR_GCOUNT, 1);
+                if (o2 == a.f.B - 1) {
+                    ag_st(a.f.bar + BAR_GCOUNT, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    ag_add(pollw, 1);
+                    released = true;
+                }
+            } else {
+                ag_add(pollw, 1);
+                released = true;
+            }
+        }
+        if (!released && ok) {
+            int it = 0;
+            while (ag_ld(pollw) == my_gen) {
+                if (++it > a.spin_limit) {
+                    ok = 0;
+                    ag_st(a.f.bar + BAR_ERR, 1);
+                    dev_err_raise(a.dev_err, DP_DEVERR_BARRIER);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        sflag[0] = ok;
+        if (!ok) sflag[1] = 1;
+    }
+    __syncthreads();
+    return sflag[0] != 0;
+}
+
+// ---- the exact 3-plane bf16 split of PT [rows][ct] (LDS) into the graph's Vs block (dp_agg.hip layout
+// Vs[plane][cb][k8][c][j]), k8 groups [k8_0, k8_0 + nk8) where local row lr = (k8 - k8_0) * 8; rows >= nrows and columns
+// >= ct are written as zeros.  One 16-byte store per (plane, cb, k8, c).
+__device__ inline void l0_write_split(ScBuf vsb, const float* PT, int ct, int CTt, int K8, int k8_0, int nk8, int nrows) {
+    const long pl = (long)CTt * K8 * 128;                   // elements per plane
+    const int items = nk8 * CTt * 16;
+    for (int item = threadIdx.x; item < items; item += L0_NT) {
+        const int c = item & 15, t = item >> 4;
+        const int k8l = t / CTt, cb = t - k8l * CTt;
+        const int vc = cb * 16 + c, lr = k8l * 8;
+        u16x8 h, m, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = (vc < ct && lr + j < nrows) ? PT[(lr + j) * ct + min(vc, ct - 1)] : 0.f;
+            unsigned short hh, mm, ll;
+            bf16_split3(v, hh, mm, ll);
+            h[j] = hh; m[j] = mm; l[j] = ll;
+        }
+        const long o = vs_index(0, CTt, K8, cb, k8_0 + k8l, c, 0);
+        sc_st16(vsb, (unsigned)(o * 2), __builtin_bit_cast(u32x4, h));
+        sc_st16(vsb, (unsigned)((o + pl) * 2), __builtin_bit_cast(u32x4, m));
+        sc_st16(vsb, (unsigned)((o + 2 * pl) * 2), __builtin_bit_cast(u32x4, l));
+    }
+}
+
+// ---- aggregation  acc += Ablk[RB x N] . V[N x cols cb0*16 ..),  Ablk bf16 in LDS, V as 3 bf16 planes from global (sc1).
+// Wave (kh = wave & 3, ch = wave >> 2): k-steps kh, kh + 4, ...; column tiles cb0 .. cb0 + CTH - 1 (clamped duplicates
+// beyond the operand's last tile: the caller ignores them).
+template <int MI, int CTH>
+__device__ __forceinline__ void l0_agg_bf16(const unsigned short* Alds, int ldp, ScBuf vsb, int CTt, int K8, int steps,
+                                            int cb0, f32x4 (&acc)[MI][CTH]) {
+    const int lane = threadIdx.x & 63;
+    const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
+    const int l15 = lane & 15, kq = lane >> 4;
+    s16x8 f0[3][CTH], f1[3][CTH];
+    auto load_b = [&](int step, s16x8 (&dst)[3][CTH]) {
+        const int st = min(step, steps - 1);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int cbi = 0; cbi < CTH; ++cbi) {
+                const int cb = min(cb0 + cbi, CTt - 1);
+                const long o = ((((long)p * CTt + cb) * K8 + st * 4 + kq) * 16 + l15) * 8;
+                dst[p][cbi] = __builtin_bit_cast(s16x8, sc_ld16(vsb, (unsigned)(o * 2)));
+            }
+    };
+    auto mma = [&](int step, const s16x8 (&bf)[3][CTH]) {
+        s16x8 av[MI];
+#pragma unroll
+        for (int rb = 0; rb < MI; ++rb)
+            av[rb] = *reinterpret_cast<const s16x8*>(Alds + (rb * 16 + l15) * ldp + step * 32 + kq * 8);
+#pragma unroll
+        for (int p = 2; p >= 0; --p)          // lo, mid, hi: small terms first
+#pragma unroll
+            for (int rb = 0; rb < MI; ++rb)
+#pragma unroll
+                for (int cbi = 0; cbi < CTH; ++cbi)
+                    acc[rb][cbi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[rb]),
+                                                                           __builtin_bit_cast(bf16x8, bf[p][cbi]),
+                                                                           acc[rb][cbi], 0, 0, 0);
+    };
+    load_b(kh, f0);
+    load_b(kh + 4, f1);
+    for (int step = kh; step < steps; step += 8) {
+        mma(step, f0);
+        if (step + 4 < steps) {
+            load_b(step + 8, f0);
+            mma(step + 4, f1);
+            load_b(step + 12, f1);
+        }
+    }
+}
+
+// The same product for a graph whose adjacency is not bf16-exact: fp32 MFMA, op(A) rows straight from the fp32 input
+// in global memory (element (i, k) at Ag[i * rs + k * ks]: rs = N, ks = 1 for A; rs = 1, ks = N for A^T), V rebuilt
+// exactly from its planes (hi + mid + lo == v).  Slow; only weighted adjacency ever comes here.
+template <int MI, int CTH>
+__device__ __forceinline__ void l0_agg_f32(const float* Ag, long rs, long ks, int nrows, int N, ScBuf vsb, int CTt, int K8,
+                                           int steps, int cb0, f32x4 (&acc)[MI][CTH]) {
+    const int lane = threadIdx.x & 63;
+    const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
+    const int l15 = lane & 15, kq = lane >> 4;
+    for (int step = kh; step < steps; step += 4) {
+        float bv[CTH][8];
+#pragma unroll
+        for (int cbi = 0; cbi < CTH; ++cbi) {
+            const int cb = min(cb0 + cbi, CTt - 1);
+            u16x8 pl3[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const long o = ((((long)p * CTt + cb) * K8 + step * 4 + kq) * 16 + l15) * 8;
+                pl3[p] = __builtin_bit_cast(u16x8, sc_ld16(vsb, (unsigned)(o * 2)));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                bv[cbi][j] = (__uint_as_float((unsigned)pl3[0][j] << 16) + __uint_as_float((unsigned)pl3[1][j] << 16)) +
+                             __uint_as_float((unsigned)pl3[2][j] << 16);
+        }
+#pragma unroll
+        for (int rb = 0; rb < MI; ++rb) {
+            const int i = rb * 16 + l15;
+            float av[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = step * 32 + kq * 8 + j;
+                const float t = Ag[(long)min(i, nrows - 1) * rs + (long)min(k, N - 1) * ks];
+                av[j] = (i < nrows && k < N) ? t : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int cbi = 0; cbi < CTH; ++cbi)
+                    acc[rb][cbi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[cbi][j], acc[rb][cbi], 0, 0, 0);
+        }
+    }
+}
+
+// One aggregation pass into the k-quarter slots red[kh][RB][ctp] (the caller sums the four quarters).
+template <int MI, int CTH>
+__device__ __forceinline__ void l0_aggregate_pass(const L0Args& a, const unsigned short* Alds, bool exact, const float* Ag,
+                                                  long rs, long ks, int nrows, ScBuf vsb, int CTt, float* red, int ctp) {
+    constexpr int RB = MI * 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kh = wave & 3, ch = wave >> 2;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int cta = (CTt + 1) >> 1;                        // column tiles of half 0
+    const int cb0 = ch ? cta : 0, ncb = ch ? CTt - cta : cta;
+    f32x4 acc[MI][CTH];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < CTH; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ncb > 0) {
+        if (exact) l0_agg_bf16<MI, CTH>(Alds, a.ldp, vsb, CTt, a.K8, a.steps, cb0, acc);
+        else l0_agg_f32<MI, CTH>(Ag, rs, ks, nrows, a.f.N, vsb, CTt, a.K8, a.steps, cb0, acc);
+    }
+#pragma unroll
+    for (int rb = 0; rb < MI; ++rb)
+#pragma unroll
+        for (int cbi = 0; cbi < CTH; ++cbi)
+            if (cbi < ncb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[(kh * RB + rb * 16 + kq * 4 + r) * ctp + (cb0 + cbi) * 16 + l15] = acc[rb][cbi][r];
+            }
+}
+template <int MI>
+__device__ __forceinline__ void l0_aggregate(const L0Args& a, const unsigned short* Alds, bool exact, const float* Ag, long rs,
+                                             long ks, int nrows, ScBuf vsb, int CTt, float* red, int ctp) {
+    const int cth = (CTt + 1) >> 1;
+    if (cth <= 1) l0_aggregate_pass<MI, 1>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp);
+    else if (cth == 2) l0_aggregate_pass<MI, 2>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp);
+    else l0_aggregate_pass<MI, 3>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp);
+}
+
+// 16-byte-quad staging of RB rows of a bf16 operand [*, ld] into the LDS adjacency block (sc1 loads; columns >= ld and
+// rows >= nrows become zeros up to the k-step padding): issue() asks for everything, commit() writes LDS.
+template <int MI>
+struct L0RowStage {
+    static constexpr int NQ = 2 * MI;                      // rows tr, tr + 8, ... of one 512-column segment
+    u32x4 q[NQ];
+};
+template <int MI>
+__device__ __forceinline__ void l0_stage_issue(L0RowStage<MI>& s, ScBuf buf, long row0_elems, int ld, int nrows, int seg) {
+    const int tq = threadIdx.x & 63, tr = threadIdx.x >> 6;
+    const int c8 = seg * 64 + tq;
+#pragma unroll
+    for (int u = 0; u < L0RowStage<MI>::NQ; ++u) {
+        const int row = min(tr + 8 * u, max(nrows - 1, 0));
+        const int cc = min(c8 * 8, ld - 8);
+        s.q[u] = sc_ld16(buf, (unsigned)((row0_elems + (long)row * ld + cc) * 2));
+    }
+}
+template <int MI>
+__device__ __forceinline__ void l0_stage_commit(const L0RowStage<MI>& s, unsigned short* Alds, int ldp, int ld, int nrows, int seg) {
+    const int tq = threadIdx.x & 63, tr = threadIdx.x >> 6;
+    const int c8 = seg * 64 + tq;
+#pragma unroll
+    for (int u = 0; u < L0RowStage<MI>::NQ; ++u) {
+        const int row = tr + 8 * u;
+        const bool in = row < nrows && c8 * 8 < ld;
+        const u32x4 v = in ? s.q[u] : (u32x4){0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(Alds + row * ldp + c8 * 8) = v;
+    }
+}
+
+template <int MI>
+__global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
+    constexpr int RB = MI * 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Level0Fwd& f = a.f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tl = tid & 15, team = tid >> 4;
+    const int N = f.N, G = f.G, L = f.L;
+    // XCD-aware work mapping (as k_aggregate): every XCD gets one contiguous run of (graph, row block) items, so a
+    // graph's blocks share one L2 for the split operand they all read
+    int wid;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qd = nwg >> 3, rm = nwg & 7;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int b = wid / a.T, rb = wid - b * a.T;
+    const int r0 = rb * RB;
+    const int nrows = min(RB, N - r0);                      // valid rows of this block (>= 1)
+    const int nb = f.num_nodes ? min(f.num_nodes[b], N) : N;
+    L0_STAMP(0);
+
+    unsigned short* Alds = reinterpret_cast<unsigned short*>(lds);              // [RB][ldp] bf16
+    float* ACT0 = lds + a.lds_act[0];                      // [RB][ldz[0]]  this block's rows of Ze
+    float* ACT1 = lds + a.lds_act[1];                      // [RB][ldz[1]]  ... of Za
+    float* SCR = lds + a.lds_scr;
+    int* sflag = reinterpret_cast<int*>(lds + a.lds_scr + a.scr_floats);       // [0] ok, [1] failed, [2] block flag
+    if (tid < 4) sflag[tid] = 0;
+    __syncthreads();
+
+    // the graph's block of the split operand: laid out per pass for that pass's column-tile count (dp_agg.hip layout)
+    auto vs_of = [&](int CTt) {
+        return sc_buf(f.vs + (long)b * 3 * CTt * a.K8 * 128, (size_t)3 * CTt * a.K8 * 128 * 2);
+    };
+    const ScBuf partb = sc_buf(f.part, (size_t)f.B * N * G * 2 * sizeof(float));
+
+    // ------------------------------------------------------------------ phase 0
+    // side jobs: clear the backward accumulators, the pooled level's barrier block, last call's error word
+    if (f.zero_p) {
+        uint4* zp = reinterpret_cast<uint4*>(f.zero_p);
+        const long nwg = gridDim.x, per = (a.zero_n16 + nwg - 1) / nwg;
+        const long end = min(a.zero_n16, ((long)wid + 1) * per);
+        for (long i = (long)wid * per + tid; i < end; i += L0_NT) zp[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (wid == 0) {
+        if (f.next_bar && tid < 64) f.next_bar[tid] = 0;
+        if (tid == 64) ag_st(f.bar + BAR_ERR, 0);
+    }
+    L0_STAMP(1);
+    const int din0[2] = {f.st[0].dims[0], G == 2 ? f.st[1].dims[0] : 0};
+    // (a) my rows of the fp32 adjacency -> bf16: LDS block, packed A rows, exactness
+    bool bad = false;
+    {
+        const float* Ab = f.A + ((long)b * N + r0) * N;
+        unsigned short* Pb = f.pkA + ((long)b * N + r0) * f.pk_ld;
+        const int tq = tid & 127, tr = tid >> 7;           // 128 column quads x 4 row lanes
+        const int segs = (a.steps * 32 + 511) / 512;
+        for (int seg = 0; seg < segs; ++seg) {
+            const int c = seg * 512 + 4 * tq;
+            f32x4_u v[4 * MI];
+#pragma unroll
+            for (int u = 0; u < 4 * MI; ++u)
+                v[u] = *reinterpret_cast<const f32x4_u*>(Ab + (long)min(tr + 4 * u, nrows - 1) * N + min(c, N - 4));
+#pragma unroll
+            for (int u = 0; u < 4 * MI; ++u) {
+                const int row = tr + 4 * u;
+                const bool in = row < nrows && c < N;
+                u16x4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned bits = in ? __float_as_uint(v[u][j]) : 0u;
+                    bad |= (bits & 0xFFFFu) != 0;
+                    h[j] = (unsigned short)(bits >> 16);
+                }
+                if (c < a.ldp) *reinterpret_cast<u16x4*>(Alds + row * a.ldp + c) = h;
+                if (row < nrows && c < f.pk_ld) *reinterpret_cast<u16x4*>(Pb + (long)row * f.pk_ld + c) = h;
+            }
+        }
+    }
+    L0_STAMP(2);
+    if (__any(bad) && lane == 0) sflag[2] = 1;
+    // (b) layer-0 inputs and weights -> LDS scratch:  X_g [RB][din], W_g [din][dout]
+    float* X0s[2];
+    float* W0s[2];
+    float* PT;
+    {
+        float* p = SCR;
+        for (int g = 0; g < G; ++g) {
+            X0s[g] = p;
+            p += RB * din0[g];
+        }
+        for (int g = 0; g < G; ++g) {
+            W0s[g] = p;
+            p += din0[g] * f.st[g].dims[1];
+        }
+        PT = p;
+        for (int g = 0; g < G; ++g) {
+            {
+                const float* xg = f.x0[g] + ((long)b * N + r0) * din0[g];
+                const int cnt = nrows * din0[g];
+                for (int e = tid; e < RB * din0[g]; e += L0_NT) X0s[g][e] = e < cnt ? xg[min(e, cnt - 1)] : 0.f;
+            }
+            const float* wg = f.params + f.st[g].w_off[0];
+            for (int e = tid; e < din0[g] * f.st[g].dims[1]; e += L0_NT) W0s[g][e] = wg[e];
+        }
+    }
+    __syncthreads();
+    L0_STAMP(3);
+    const bool blk_bad = sflag[2] != 0;
+    if (blk_bad && tid == 0) {
+        ag_st(f.bar + BAR_GRAPH0 + b * BAR_GSTRIDE + 32, 1);
+        ag_st(f.bar + BAR_GFLAG, 1);
+    }
+    // (c) my column strip of A^T: rows k of the packed transpose get my RB rows as 8-element (16-byte) pieces
+    {
+        const ScBuf atb = sc_buf(f.pkAt + (long)b * N * f.pk_ld, (size_t)N * f.pk_ld * 2);
+        constexpr int P8 = RB / 8;
+        for (int e = tid; e < N * P8; e += L0_NT) {
+            const int k = e / P8, i8 = e - k * P8;
+            if (r0 + i8 * 8 < f.pk_ld) {
+                u16x8 h;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h[j] = Alds[(i8 * 8 + j) * a.ldp + k];
+                sc_st16(atb, (unsigned)(((long)k * f.pk_ld + r0 + i8 * 8) * 2), __builtin_bit_cast(u32x4, h));
+            }
+        }
+    }
+    L0_STAMP(4);
+    // (d) P_0 = [x_e W_e | x_a W_a] of my rows, then its split
+    int ct = f.st[0].dims[1] + (G == 2 ? f.st[1].dims[1] : 0);
+    for (int g = 0; g < G; ++g) {
+        const int dout = f.st[g].dims[1], c0 = g ? f.st[0].dims[1] : 0;
+        l0_mma<false, false>(X0s[g], din0[g], W0s[g], dout, RB, dout, din0[g],
+                             [&](int r, int c, float v) { PT[r * ct + c0 + c] = v; }, g * 3);
+    }
+    __syncthreads();
+    L0_STAMP(5);
+    {
+        const int CTt = (ct + 15) / 16;
+        const int k8_0 = r0 / 8;
+        const int nk8 = min(rb == a.T - 1 ? a.K8 - k8_0 : RB / 8, a.K8 - k8_0);
+        l0_write_split(vs_of(CTt), PT, ct, CTt, a.K8, k8_0, nk8, nrows);
+    }
+    L0_STAMP(6);
+    bool ok = l0_barrier<false>(a, b, sflag);
+    L0_STAMP(7);
+    const bool exact = ag_ld(f.bar + BAR_GRAPH0 + b * BAR_GSTRIDE + 32) == 0;
+    const float* Arows = f.A + ((long)b * N + r0) * N;             // fp32 fallback operands
+    const float* Acols = f.A + (long)b * N * N + r0;
+
+    // ------------------------------------------------------------------ the GraphConv layers
+    constexpr int ITEMS = (RB * 2 + L0_TEAMS - 1) / L0_TEAMS;      // (row, group) items per team
+    for (int l = 0; l < L; ++l) {
+        const bool last = l == L - 1;
+        const int w[2] = {f.st[0].dims[l + 1], G == 2 ? f.st[1].dims[l + 1] : 0};
+        const int c0g[2] = {0, w[0]};
+        const int CTt = (ct + 15) / 16;
+        const int ctp = CTt * 16 + 1;
+        float* red = SCR;
+        // U = A_rows . P_l   (four k-quarter partials)
+        l0_aggregate<MI>(a, Alds, exact, Arows, N, 1, nrows, vs_of(CTt), CTt, red, ctp);
+        L0_STAMP(8 + 8 * l);
+        // next layer's weights go to LDS behind the reduce slots now: their latency hides under the tail
+        int wn[2] = {0, 0};
+        float* Wn[2] = {red + 4 * RB * ctp, nullptr};
+        if (!last) {
+            for (int g = 0; g < G; ++g) wn[g] = f.st[g].dims[l + 1] * f.st[g].dims[l + 2];
+            Wn[1] = Wn[0] + wn[0];
+            for (int e = tid; e < wn[0] + wn[1]; e += L0_NT)
+                Wn[0][e] = e < wn[0] ? f.params[f.st[0].w_off[l + 1] + e] : f.params[f.st[1].w_off[l + 1] + e - wn[0]];
+        }
+        __syncthreads();
+        L0_STAMP(9 + 8 * l);
+        // tail: + bias, l2-normalise, save, BatchNorm partials — one 16-lane team per (row, group); y also goes to the
+        // layer's slice of the LDS activation rows (BatchNorm rewrites it in place after the exchange)
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            float yv[L0_NK];
+            const int it = team + j * L0_TEAMS;
+            const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+            const bool on = it < RB * G && r < nrows;
+            const long row = (long)b * N + min(r0 + r, N - 1);
+            const int wg = w[g];
+            const float* bias = f.st[g].b_off[l] >= 0 ? f.params + f.st[g].b_off[l] : nullptr;
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                const int c = min(tl + 16 * k, wg - 1);
+                const int o = r * ctp + c0g[g] + c;
+                float v = (red[o] + red[RB * ctp + o]) + (red[2 * RB * ctp + o] + red[3 * RB * ctp + o]);
+                if (bias) v += bias[c];
+                v = tl + 16 * k < wg ? v : 0.f;
+                yv[k] = v;
+                ss += v * v;
+            }
+            ss = row16_sum(ss);
+            const float inv = 1.f / fmaxf(sqrtf(ss), L0_L2_EPS);
+            float s1 = 0.f;
+            float* yg = last ? f.Z[g] + row * f.ldz[g] + f.coff[g][l] : f.Y[l] + row * ct + c0g[g];
+            float* act = (g ? ACT1 : ACT0) + r * f.ldz[g] + f.coff[g][l];
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                const int c = tl + 16 * k;
+                yv[k] *= inv;
+                if (on && c < wg) yg[c] = yv[k];
+                if (it < RB * G && c < wg) act[c] = r < nrows ? yv[k] : 0.f;
+                s1 += fmaxf(yv[k], 0.f);
+            }
+            if (on && tl == 0) f.invn[l][row * G + g] = inv;
+            if (!last && f.bn) {
+                s1 = row16_sum(s1);
+                const float mean = s1 / (float)wg;
+                float m2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < L0_NK; ++k) {
+                    const float v = (tl + 16 * k < wg) ? fmaxf(yv[k], 0.f) - mean : 0.f;
+                    m2 += v * v;
+                }
+                m2 = row16_sum(m2);
+                if (on && tl == 0) {
+                    sc_stf(partb, (unsigned)(((row * G + g) * 2) * 4), mean);
+                    sc_stf(partb, (unsigned)(((row * G + g) * 2 + 1) * 4), m2);
+                }
+            }
+        }
+        L0_STAMP(10 + 8 * l);
+        if (last) break;
+        // ---- apply_bn: every graph's partials of my node indices (grid barrier), then x = (relu(y) - mu) * rstd
+        if (f.bn) ok = l0_barrier<true>(a, b, sflag) && ok;
+        else __syncthreads();
+        L0_STAMP(11 + 8 * l);
+        const int ctn = f.st[0].dims[l + 2] + (G == 2 ? f.st[1].dims[l + 2] : 0);
+        float* PTn = Wn[0] + wn[0] + wn[1];                // behind the weights (which sit behind the reduce slots)
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int it = team + j * L0_TEAMS;
+            const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+            const bool on = it < RB * G && r < nrows;
+            const int node = min(r0 + r, N - 1);
+            const long row = (long)b * N + node;
+            const int wg = w[g];
+            float mu = 0.f, rstd = 1.f;
+            if (f.bn) {
+                float pm[L0_BPAIRS], pq[L0_BPAIRS];
+#pragma unroll
+                for (int u = 0; u < L0_BPAIRS; ++u) {
+                    const long o = ((((long)min(tl + 16 * u, f.B - 1) * N + node) * G + g) * 2) * 4;
+                    pm[u] = sc_ldf(partb, (unsigned)o);
+                    pq[u] = sc_ldf(partb, (unsigned)(o + 4));
+                }
+                float sm = 0.f;
+#pragma unroll
+                for (int u = 0; u < L0_BPAIRS; ++u) sm += (tl + 16 * u < f.B) ? pm[u] : 0.f;
+                mu = row16_sum(sm) / (float)f.B;
+                float s2 = 0.f;
+#pragma unroll
+                for (int u = 0; u < L0_BPAIRS; ++u) {
+                    const float d = pm[u] - mu;
+                    s2 += (tl + 16 * u < f.B) ? pq[u] + (float)wg * d * d : 0.f;
+                }
+                const float var = row16_sum(s2) / ((float)f.B * (float)wg);
+                rstd = 1.0f / sqrtf(var + L0_BN_EPS);
+                if (!ok) mu = rstd = __builtin_nanf("");
+                if (on && b == 0 && tl == 0) {
+                    f.stats[l][((long)node * G + g) * 2] = mu;
+                    f.stats[l][((long)node * G + g) * 2 + 1] = rstd;
+                }
+            }
+            float* xg = f.Z[g] + row * f.ldz[g] + f.coff[g][l];
+            float* act = (g ? ACT1 : ACT0) + r * f.ldz[g] + f.coff[g][l];
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                const int c = tl + 16 * k;
+                const float xv = (fmaxf(act[min(c, wg - 1)], 0.f) - mu) * rstd;
+                if (on && c < wg) xg[c] = xv;
+                if (it < RB * G && c < wg) act[c] = r < nrows ? xv : 0.f;
+            }
+        }
+        __syncthreads();
+        L0_STAMP(12 + 8 * l);
+        // ---- P_{l+1} = [x_e W_e | x_a W_a] of my rows and its split
+        for (int g = 0; g < G; ++g) {
+            const int din = f.st[g].dims[l + 1], dout = f.st[g].dims[l + 2], c0 = g ? f.st[0].dims[l + 2] : 0;
+            l0_mma<false, false>((g ? ACT1 : ACT0) + f.coff[g][l], f.ldz[g], Wn[g], dout, RB, dout, din,
+                                 [&](int r, int c, float v) { PTn[r * ctn + c0 + c] = v; }, g * 3);
+        }
+        __syncthreads();
+        L0_STAMP(13 + 8 * l);
+        {
+            const int CTn = (ctn + 15) / 16;
+            const int k8_0 = r0 / 8;
+            const int nk8 = min(rb == a.T - 1 ? a.K8 - k8_0 : RB / 8, a.K8 - k8_0);
+            l0_write_split(vs_of(CTn), PTn, ctn, CTn, a.K8, k8_0, nk8, nrows);
+        }
+        L0_STAMP(14 + 8 * l);
+        ok = l0_barrier<false>(a, b, sflag) && ok;
+        L0_STAMP(15 + 8 * l);
+        ct = ctn;
+    }
+    __syncthreads();                                       // the last layer's rows are in ACT0 / ACT1
+
+    const int K = f.K, D = f.ldz[0];
+    float* XP = SCR;                                       // partial X' [K][D] | A' [K][K] (after the A^T S pass)
+    if (G == 2 && K > 0) {
+        // ------------------------------------------------------------------ assign head + softmax + mask
+        const int Da = f.ldz[1];
+        const int CTk = (K + 15) / 16, ctpk = CTk * 16 + 1;
+        float* TL = SCR + 4 * RB * ctpk;                   // [RB][K]  T rows        (beyond the reduce slots of the A^T S pass)
+        float* SL = TL + RB * K;                           // [RB][K]  logits, then S rows
+        float* WP = SCR;                                   // [K][Da]  (the reduce area is free now)
+        {
+            const float* wp = f.params + f.wp_off;
+            for (int e = tid; e < K * Da; e += L0_NT) WP[e] = wp[e];
+        }
+        __syncthreads();
+        L0_STAMP(40);
+        {
+            const float* bp = f.bp_off >= 0 ? f.params + f.bp_off : nullptr;
+            l0_mma<false, true>(ACT1, Da, WP, Da, RB, K, Da,
+                                [&](int r, int c, float v) { SL[r * K + c] = bp ? v + bp[c] : v; });
+        }
+        __syncthreads();
+        L0_STAMP(41);
+        for (int r = team; r < RB; r += L0_TEAMS) {
+            const int node = r0 + r;
+            const bool valid = node < nb;
+            float lv[L0_NK];
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) lv[k] = SL[r * K + min(tl + 16 * k, K - 1)];
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) m = fmaxf(m, lv[k]);
+            m = row16_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                lv[k] = expf(lv[k] - m);
+                sum += (tl + 16 * k < K) ? lv[k] : 0.f;
+            }
+            sum = row16_sum(sum);
+            const float rinv = 1.f / sum;
+            const long row = (long)b * N + min(node, N - 1);
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                const int c = tl + 16 * k;
+                if (c < K) {
+                    const float v = (valid && node < N) ? lv[k] * rinv : 0.f;
+                    SL[r * K + c] = v;
+                    if (node < N) {
+                        f.S[row * K + c] = v;
+                        if (f.S2) f.S2[row * K + c] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        L0_STAMP(42);
+        {
+            const int k8_0 = r0 / 8;
+            const int nk8 = min(rb == a.T - 1 ? a.K8 - k8_0 : RB / 8, a.K8 - k8_0);
+            l0_write_split(vs_of(CTk), SL, K, CTk, a.K8, k8_0, nk8, nrows);
+        }
+        L0_STAMP(43);
+        // my rows of A^T replace my rows of A (every wave is past the last GraphConv pass): asked for in front of the
+        // barrier, written to LDS behind it
+        {
+            const int segs = (a.steps * 32 + 511) / 512;
+            const ScBuf atb = sc_buf(f.pkAt + (long)b * N * f.pk_ld, (size_t)N * f.pk_ld * 2);
+            L0RowStage<MI> atq;
+            l0_stage_issue<MI>(atq, atb, (long)r0 * f.pk_ld, f.pk_ld, nrows, 0);
+            ok = l0_barrier<false>(a, b, sflag) && ok;
+            L0_STAMP(44);
+            l0_stage_commit<MI>(atq, Alds, a.ldp, f.pk_ld, nrows, 0);
+            for (int seg = 1; seg < segs; ++seg) {
+                l0_stage_issue<MI>(atq, atb, (long)r0 * f.pk_ld, f.pk_ld, nrows, seg);
+                l0_stage_commit<MI>(atq, Alds, a.ldp, f.pk_ld, nrows, seg);
+            }
+        }
+        __syncthreads();
+        L0_STAMP(45);
+        // ------------------------------------------------------------------ T = A^T S (my rows), partial X', A'
+        l0_aggregate<MI>(a, Alds, exact, Acols, 1, N, nrows, vs_of(CTk), CTk, SCR, ctpk);
+        L0_STAMP(46);
+        __syncthreads();
+        L0_STAMP(47);
+        for (int r = team; r < RB; r += L0_TEAMS) {
+            const long row = (long)b * N + min(r0 + r, N - 1);
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                const int c = tl + 16 * k;
+                const int o = r * ctpk + min(c, K - 1);
+                const float v = (SCR[o] + SCR[RB * ctpk + o]) + (SCR[2 * RB * ctpk + o] + SCR[3 * RB * ctpk + o]);
+                if (c < K) {
+                    TL[r * K + c] = r < nrows ? v : 0.f;
+                    if (r < nrows) f.Tt[row * K + c] = v;
+                }
+            }
+        }
+        __syncthreads();
+        L0_STAMP(48);
+        float* AP = XP + K * D;
+        l0_mma<true, false>(SL, K, ACT0, D, K, D, RB, [&](int i, int j, float v) { XP[i * D + j] = v; });
+        l0_mma<true, false>(TL, K, SL, K, K, K, RB, [&](int i, int j, float v) { AP[i * K + j] = v; }, 4);
+        for (int e = K * D + K * K + tid; e < a.epad; e += L0_NT) XP[e] = 0.f;
+        __syncthreads();
+        L0_STAMP(49);
+        {
+            const ScBuf xpb = sc_buf(f.xpart + ((long)b * a.T + rb) * a.epad, (size_t)a.epad * 4);
+            for (int e4 = tid; e4 < a.epad / 4; e4 += L0_NT)
+                sc_st16(xpb, (unsigned)(e4 * 16), *reinterpret_cast<const u32x4*>(XP + e4 * 4));
+        }
+    }
+    // ------------------------------------------------------------------ max readout: partial over my rows
+    if (f.do_max) {
+        const int nm = f.mask_readout ? max(min(nb - r0, nrows), 0) : nrows;   // rows that take part
+        const ScBuf mpb = sc_buf(f.mpart + ((long)b * a.T + rb) * f.rw * 2, (size_t)f.rw * 2 * 4);
+        for (int c = tid; c < f.rw; c += L0_NT) {
+            float best = -INFINITY;
+            int bi = -1;
+            for (int r = 0; r < nm; ++r) {
+                const float v = ACT0[r * D + f.zoff + c];
+                if (v > best) {
+                    best = v;
+                    bi = r0 + r;
+                }
+            }
+            sc_stf(mpb, (unsigned)(c * 8), best);
+            sc_stf(mpb, (unsigned)(c * 8 + 4), __int_as_float(bi));
+        }
+    }
+    L0_STAMP(50);
+    if ((G == 2 && K > 0) || f.do_max) ok = l0_barrier<false>(a, b, sflag) && ok;
+    L0_STAMP(51);
+    // ------------------------------------------------------------------ combine (block order: deterministic)
+    if (G == 2 && K > 0) {
+        const int n4 = a.epad / 4;
+        const int per = (n4 + a.T - 1) / a.T;
+        const ScBuf xgb = sc_buf(f.xpart + (long)b * a.T * a.epad, (size_t)a.T * a.epad * 4);
+        for (int i = tid; i < per; i += L0_NT) {
+            const int e4 = rb * per + i;
+            if (e4 < n4) {
+                f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < a.T; ++t) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, sc_ld16(xgb, (unsigned)(((long)t * a.epad + e4 * 4) * 4)));
+                    s += v;
+                }
+                if (!ok) s = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e4 * 4 + j;
+                    if (e < K * D) f.Xn[(long)b * K * D + e] = s[j];
+                    else if (e < K * D + K * K) f.An[(long)b * K * K + e - K * D] = s[j];
+                }
+            }
+        }
+    }
+    if (f.do_max && rb == 0) {
+        const ScBuf mgb = sc_buf(f.mpart + (long)b * a.T * f.rw * 2, (size_t)a.T * f.rw * 2 * 4);
+        for (int c = tid; c < f.rw; c += L0_NT) {
+            float best = -INFINITY;
+            int bi = -1;
+            for (int t = 0; t < a.T; ++t) {
+                const float v = sc_ldf(mgb, (unsigned)((((long)t * f.rw + c) * 2) * 4));
+                const int i = __float_as_int(sc_ldf(mgb, (unsigned)((((long)t * f.rw + c) * 2 + 1) * 4)));
+                if (i >= 0 && v > best) {            // blocks come in row order: strict > keeps the lowest row on ties
+                    best = v;
+                    bi = i;
+                }
+            }
+            if (f.mask_readout && nb < N && !(best > 0.f)) {   // a masked (zero) row wins unless a valid row ties it at 0
+                if (best < 0.f || bi < 0) {
+                    best = 0.f;
+                    bi = -1;
+                }
+            }
+            if (!ok) best = __builtin_nanf("");
+            f.feat[(long)b * f.ldfeat + f.featoff + c] = best;
+            f.argmax[(long)b * f.rw + c] = bi;
+        }
+    }
+    // ------------------------------------------------------------------ the last workgroup to finish cleans up
+    __syncthreads();
+    L0_STAMP(52);
+    if (tid == 0) {
+        const int old = ag_add(f.bar + BAR_DONE, 1);
+        sflag[3] = old == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (sflag[3]) {
+        const int gflag = ag_ld(f.bar + BAR_GFLAG);
+        if (tid < 64) f.pk_flag[tid] = tid == 0 ? gflag : 0;
+        for (int g = tid; g < f.B; g += L0_NT) {
+            ag_st(f.bar + BAR_GRAPH0 + g * BAR_GSTRIDE, 0);
+            ag_st(f.bar + BAR_GRAPH0 + g * BAR_GSTRIDE + 32, 0);
+        }
+        if (tid == 0) {
+            ag_st(f.bar + BAR_GCOUNT, 0);
+            ag_st(f.bar + BAR_GFLAG, 0);
+            ag_st(f.bar + BAR_DONE, 0);
+        }
+    }
+}
+
+struct L0Geom {
+    int RB, T, ldp, K8, steps, epad;
+    int lds_act[2], lds_scr, scr_floats;
+    size_t lds_bytes;
+};
+int l0_device_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        hipDeviceProp_t prop;
+        v = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : -1;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v > 0 ? v : 0;
+}
+// Rows per block, LDS layout.  Returns false when no block size fits (LDS, or more workgroups than CUs).
+bool l0_geometry(const Level0Fwd& f, L0Geom& g) {
+    const int cus = l0_device_cus();
+    if (cus <= 0) return false;
+    const int N = f.N, G = f.G, L = f.L;
+    g.steps = (N + 31) / 32;
+    g.K8 = g.steps * 4;
+    g.ldp = ((N + 511) / 512) * 512 + 8;
+    const int K = G == 2 ? f.K : 0, D = f.ldz[0];
+    g.epad = (K * D + K * K + 3) & ~3;
+    for (int RB = 16; RB <= 64; RB += 16) {
+        const int T = (N + RB - 1) / RB;
+        if ((long)f.B * T > cus) continue;
+        size_t scr = 0;
+        auto need = [&](size_t fl) { scr = fl > scr ? fl : scr; };
+        // phase 0: X rows, W, PT
+        {
+            size_t fl = 0;
+            for (int s = 0; s < G; ++s)        // (both stacks' inputs are staged even when they are the same tensor: the
+                fl += (size_t)RB * f.st[s].dims[0] + (size_t)f.st[s].dims[0] * f.st[s].dims[1];   // layout must not depend on pointers)
+            int ct = 0;
+            for (int s = 0; s < G; ++s) ct += f.st[s].dims[1];
+            need(fl + (size_t)RB * ct);
+        }
+        for (int l = 0; l < L; ++l) {
+            int ct = 0;
+            for (int s = 0; s < G; ++s) ct += f.st[s].dims[l + 1];
+            const size_t slots = (size_t)4 * RB * (((ct + 15) / 16) * 16 + 1);   // reduce slots
+            need(slots);
+            if (l < L - 1) {
+                size_t fl = 0;
+                int ctn = 0;
+                for (int s = 0; s < G; ++s) {
+                    fl += (size_t)f.st[s].dims[l + 1] * f.st[s].dims[l + 2];
+                    ctn += f.st[s].dims[l + 2];
+                }
+                need(slots + fl + (size_t)RB * ctn);                       // ... | next layer's weights | P_{l+1}
+            }
+        }
+        if (K > 0) {
+            const int ctpk = ((K + 15) / 16) * 16 + 1;
+            need((size_t)4 * RB * ctpk + 2 * (size_t)RB * K);                 // reduce slots | TL | SL
+            // the staged assign_pred weight (before the pass) and the partial X' | A' (after it) overlay the slots
+            if ((size_t)K * f.ldz[1] > (size_t)4 * RB * ctpk || (size_t)g.epad > (size_t)4 * RB * ctpk) continue;
+        }
+        const size_t adj_fl = ((size_t)RB * g.ldp * 2 + 15) / 16 * 4;         // floats, 16-byte multiple
+        g.lds_act[0] = (int)adj_fl;
+        g.lds_act[1] = g.lds_act[0] + ((RB * f.ldz[0] + 3) & ~3);
+        g.lds_scr = g.lds_act[1] + (G == 2 ? ((RB * f.ldz[1] + 3) & ~3) : 0);
+        g.scr_floats = (int)((scr + 3) & ~size_t(3));
+        g.lds_bytes = ((size_t)g.lds_scr + g.scr_floats + 16) * sizeof(float);
+        if (g.lds_bytes > 159 * 1024) continue;
+        g.RB = RB;
+        g.T = T;
+        return true;
+    }
+    return false;
+}
+
+template <int MI>
+void l0_launch(Seq& q, const L0Args& a, size_t lds_bytes) {
+    static DynLdsOnce attr;
+    ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_level0_fwd<MI>), 160 * 1024, "k_level0_fwd");
+    if (!q.ok()) return;
+    hipLaunchKernelGGL(k_level0_fwd<MI>, dim3(a.f.B * a.T), dim3(L0_NT), lds_bytes, q.stream, a);
+    q.check_launch("level0_forward");
+}
+
+}  // namespace
+
+size_t level0_bar_ints(int B) { return (size_t)BAR_GRAPH0 + (size_t)BAR_GSTRIDE * B; }
+const int* level0_error_word(const int* bar) { return bar + BAR_ERR; }
+size_t level0_xpart_floats(const Level0Fwd& f) {
+    L0Geom g;
+    if (!l0_geometry(f, g)) return 4;
+    return (size_t)f.B * g.T * g.epad + 4;
+}
+size_t level0_mpart_floats(const Level0Fwd& f) {
+    L0Geom g;
+    if (!l0_geometry(f, g)) return 4;
+    return (size_t)f.B * g.T * (f.rw > 0 ? f.rw : 1) * 2 + 4;
+}
+
+// Shapes the persistent kernel takes (everything else runs as the launch sequence of rounds 1-2).
+bool level0_persistent_ok(const Level0Fwd& f) {
+    if (knobs().no_l0_persist) return false;
+    if (f.G < 1 || f.G > 2 || f.L < 1 || f.L > DP_MAX_LAYERS) return false;
+    if (f.N < 128 || (f.N & 3) || f.B < 1 || f.B > 16 * L0_BPAIRS) return false;
+    if (!adj_pack_supported(f.N, 1)) return false;
+    for (int l = 0; l < f.L; ++l) {
+        int ct = 0;
+        size_t wfl = 0;
+        for (int s = 0; s < f.G; ++s) {
+            if (f.st[s].dims[l + 1] < 1 || f.st[s].dims[l + 1] > 16 * L0_NK) return false;
+            ct += f.st[s].dims[l + 1];
+            wfl += (size_t)f.st[s].dims[l] * f.st[s].dims[l + 1];
+        }
+        if (ct > 96 || wfl > 8192) return false;              // <= 6 column tiles; a layer's weights <= 32 KiB
+    }
+    for (int s = 0; s < f.G; ++s)
+        if (f.st[s].dims[0] < 1 || f.st[s].dims[0] > 256 || f.ldz[s] > 160) return false;
+    if (f.G == 2) {
+        if (f.K < 1 || f.K > 16 * L0_NK || (size_t)f.K * f.ldz[1] > 8192) return false;
+    }
+    if (f.do_max && (f.rw < 1 || f.zoff + f.rw > f.ldz[0])) return false;
+    L0Geom g;
+    return l0_geometry(f, g);
+}
+
+void level0_forward(Seq& q, const Level0Fwd& f) {
+    if (!q.ok()) return;
+    L0Geom g;
+    if (!l0_geometry(f, g)) {
+        set_error("level0_forward: shape outside the persistent kernel's envelope");
+        q.err = DP_ERR_UNSUPPORTED;
+        return;
+    }
+    L0Args a{};
+    a.f = f;
+    a.T = g.T; a.RB = g.RB; a.ldp = g.ldp; a.K8 = g.K8; a.steps = g.steps; a.epad = g.epad;
+    a.lds_act[0] = g.lds_act[0]; a.lds_act[1] = g.lds_act[1]; a.lds_scr = g.lds_scr; a.scr_floats = g.scr_floats;
+    a.dev_err = device_error_word();
+    a.spin_limit = knobs().test_barrier_fail ? 64 : L0_SPIN_LIMIT;
+    a.target_bias = knobs().test_barrier_fail ? 1 : 0;
+    a.zero_n16 = f.zero_p ? (long)(f.zero_bytes / 16) : 0;
+    if (f.zero_p && ((reinterpret_cast<uintptr_t>(f.zero_p) & 15) != 0 || (f.zero_bytes & 15) != 0)) {
+        zero_fill(q, f.zero_p, f.zero_bytes);
+        a.f.zero_p = nullptr;
+        a.zero_n16 = 0;
+    }
+    switch (g.RB / 16) {
+        case 1: l0_launch<1>(q, a, g.lds_bytes); break;
+        case 2: l0_launch<2>(q, a, g.lds_bytes); break;
+        case 3: l0_launch<3>(q, a, g.lds_bytes); break;
+        default: l0_launch<4>(q, a, g.lds_bytes); break;
+    }
+}
+
+#ifdef DP_STAMP
+extern "C" __attribute__((visibility("default"))) int dp_debug_l0_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_l0_stamps), sizeof(unsigned long long) * 3 * 64);
+}
+#endif
+
+}  // namespace dp

@@ -782,6 +782,7 @@ size_t dropout_scratch_floats(const dp_encoder_cfg& c) {
 struct Scratch {
     float* xm[2];
     float *Pj, *Uj, *part, *part_b, *logits, *lvl_part, *part_all;
+    float *xpart, *mpart;    // persistent level-0 kernel: partial pooled products / max-readout partials
     unsigned short* vs;      // 3-plane bf16 split of the current V operand (level 0, packed adjacency)
 };
 size_t vs_elems(const dp_encoder_cfg& c) {
@@ -817,6 +818,46 @@ bool head_usable(const dp_encoder_cfg& c) {
     return head_supported(h);
 }
 
+// Level 0 as the persistent kernel sees it (dp_level0.hip).  Everything level0_persistent_ok() looks at comes from the
+// cfg, so the sizing walk and the call decide alike; pointers are filled in by the caller.
+Level0Fwd level0_desc(const dp_encoder_cfg& c) {
+    const LevelInfo li = level_info(c, 0);
+    Level0Fwd f{};
+    f.B = c.B; f.N = c.N; f.L = li.L; f.G = li.G;
+    f.bn = (c.flags & DP_F_BN) ? 1 : 0;
+    f.do_max = c.readout == 0 ? 1 : 0;
+    f.mask_readout = c.mask_readout ? 1 : 0;
+    for (int g = 0; g < li.G; ++g) {
+        const dp_stack_cfg* st = g == 0 ? li.e : li.a;
+        for (int l = 0; l <= li.L; ++l) f.st[g].dims[l] = st->dims[l];
+        for (int l = 0; l < li.L; ++l) {
+            f.st[g].w_off[l] = st->w_off[l];
+            f.st[g].b_off[l] = st->b_off[l];
+            f.coff[g][l] = g == 0 ? li.coff_e[l] : li.coff_a[l];
+        }
+    }
+    f.ldz[0] = li.D;
+    f.ldz[1] = li.Da;
+    f.K = li.K;
+    if (li.G == 2) {
+        f.wp_off = c.assign_pred_w_off[0];
+        f.bp_off = c.assign_pred_b_off[0];
+    }
+    f.rw = readout_width(c, li);
+    f.zoff = (c.flags & DP_F_LAST_ONLY) ? li.coff_e[li.L - 1] : 0;
+    f.ldfeat = c.pred_dims[0];
+    f.featoff = 0;
+    f.pk_ld = adj_pack_ld(c.N);
+    return f;
+}
+bool level0_persistent(const dp_encoder_cfg& c) {
+    if (bn_sync(c) || (c.flags & DP_F_ADD_SELF)) return false;
+    const LevelInfo li = level_info(c, 0);
+    for (int l = 0; l < li.L; ++l)
+        if (li.e->drop_off[l] >= 0 || (li.a && li.a->drop_off[l] >= 0) || layer_agg_first(li, l)) return false;
+    return level0_persistent_ok(level0_desc(c));
+}
+
 // shared allocation walk for the forward (also used for sizing)
 Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
     size_t maxPU = 0, maxPart = 0, maxLog = 0;
@@ -836,6 +877,11 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
     s.lvl_part = q.alloc<float>(level_part_floats(c));
     s.part_all = bn_sync(c) ? q.alloc<float>(maxPart * bn_world(c)) : nullptr;
     s.vs = q.alloc<unsigned short>(vs_elems(c));
+    if (level0_persistent(c)) {
+        const Level0Fwd f = level0_desc(c);
+        s.xpart = q.alloc<float>(level0_xpart_floats(f));
+        s.mpart = q.alloc<float>(level0_mpart_floats(f));
+    }
     const size_t dsf = dropout_scratch_floats(c);
     s.xm[0] = dsf ? q.alloc<float>(dsf) : nullptr;
     s.xm[1] = dsf ? q.alloc<float>(dsf) : nullptr;
@@ -848,7 +894,10 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
                     const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
                     float* assign_out, void* save, int mode, long long* labels_out) {
     SaveLayout sv = layout_save(c, save);
-    const BwdZero bz = alloc_bwd_zero(q, c);      // same offsets as in encoder_backward: first block of the workspace
+    // the persistent level-0 kernel's barrier block: first thing in the workspace in BOTH walks; zero when the workspace
+    // is first used (diffpool_hip.h), self-cleaning afterwards (dp_level0.hip)
+    int* l0_bar = q.alloc<int>(level0_bar_ints(c.B));
+    const BwdZero bz = alloc_bwd_zero(q, c);      // same offsets as in encoder_backward: next block of the workspace
     Scratch sc = fwd_scratch(q, c);
     if (q.err) return q.err;
     const int B = c.B, P = c.num_pooling;
@@ -861,8 +910,11 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
     const PackedAdj* pkp = sv.pkA ? &pk0 : nullptr;
     PackJob pack{adj, sv.pkA, sv.pkAt, sv.pk_flag, sv.pk_ld, train && !q.dry ? q.ws + bz.begin : nullptr,
                  train ? bz.end - bz.begin : 0};
-    const bool pack_in_level = pkp && !(level_is_small(B, level_info(c, 0)) && !dropout);
-    if (pkp && !pack_in_level) adj_pack(q, adj, sv.pkA, sv.pkAt, sv.pk_flag, B, c.N, sv.pk_ld, false, pack.zero_p,
+    const bool l0_persist = level0_persistent(c);
+    const bool pack_in_level = pkp && !l0_persist && !(level_is_small(B, level_info(c, 0)) && !dropout);
+    if (l0_persist) {
+        // handled below (one launch for the whole level, pack included)
+    } else if (pkp && !pack_in_level) adj_pack(q, adj, sv.pkA, sv.pkAt, sv.pk_flag, B, c.N, sv.pk_ld, false, pack.zero_p,
                                         pack.zero_bytes);
     else if (!pkp && train && !q.dry) zero_fill(q, q.ws + bz.begin, bz.end - bz.begin);
     int featoff = 0;
@@ -889,6 +941,45 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
         io.xm[0] = sc.xm[0];
         io.xm[1] = sc.xm[1];
         io.pack = (j == 0 && pack_in_level) ? &pack : nullptr;
+        if (j == 0 && l0_persist) {
+            // the whole level in ONE persistent launch: pack, GraphConv stacks, readout, assign head, pooling products
+            Level0Fwd f = level0_desc(c);
+            f.train = train ? 1 : 0;
+            f.A = adj;
+            f.x0[0] = x;
+            f.x0[1] = assign_x;
+            f.num_nodes = num_nodes;
+            f.params = params;
+            for (int l = 0; l < li.L; ++l) {
+                f.Y[l] = lv.layer[l].Y;
+                f.invn[l] = lv.layer[l].invn;
+                f.stats[l] = lv.layer[l].stats;
+            }
+            f.Z[0] = lv.Ze;
+            f.Z[1] = lv.Za;
+            f.S = lv.S; f.S2 = assign_out; f.Tt = lv.T; f.Xn = lv.Xn; f.An = lv.An;
+            f.feat = sv.feat;
+            f.argmax = lv.argmax;
+            f.pkA = sv.pkA; f.pkAt = sv.pkAt; f.pk_flag = sv.pk_flag;
+            f.vs = sc.vs; f.part = sc.part; f.xpart = sc.xpart; f.mpart = sc.mpart;
+            f.bar = l0_bar;
+            f.zero_p = train && !q.dry ? q.ws + bz.begin : nullptr;
+            f.zero_bytes = train ? bz.end - bz.begin : 0;
+            if (j < P) {
+                level_bar = q.alloc<int>(64);             // the pooled level's grid-barrier block, cleared by this launch
+                f.next_bar = level_bar;
+            }
+            level0_forward(q, f);
+            if (!q.dry) poison[n_poison++] = level0_error_word(l0_bar);
+            if (c.readout == 0) featoff += f.rw;
+            else {
+                mask_rows(q, lv.Ze, li.D, sv.Zm, li.D, num_nodes, B, li.n, li.D);
+                set2set_fwd(q, sv.Zm, li.D, PW(params, c.s2s_off[0]), PW(params, c.s2s_off[1]), PW(params, c.s2s_off[2]),
+                            PW(params, c.s2s_off[3]), PW(params, c.s2s_off[4]), PW(params, c.s2s_off[5]), sv.feat, B,
+                            li.n, li.D, sv.s2s);
+            }
+            continue;
+        }
         level_forward(q, c, li, lv, io, params, sc.Pj, sc.Uj, sc.part, sc.part_b, j == 0 ? pkp : nullptr, sc.vs,
                       sc.lvl_part, level_bar, sc.part_all);
         if (level_bar && !q.dry && !bn_sync(c) && level_is_fused(c, li, io, true)) poison[n_poison++] = level_bar + 1;
@@ -976,7 +1067,8 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     const int B = c.B, P = c.num_pooling;
     // ---- workspace walk
     size_t maxPU = 0, maxPart = 0, maxSK = 0, maxMeans = 0;
-    // zero-initialised gradient accumulators + slabs: ONE block at the start of the workspace (alloc_bwd_zero)
+    // (the forward's barrier block, then) zero-initialised gradient accumulators + slabs: ONE block (alloc_bwd_zero)
+    (void)q.alloc<int>(level0_bar_ints(c.B));
     const BwdZero bz = alloc_bwd_zero(q, c);
     LevelGrad gr[DP_MAX_LEVELS + 1]{};
     for (int j = 0; j <= P; ++j) gr[j] = bz.gr[j];

@@ -216,7 +216,9 @@ class _Plan:
         self.ws_bytes = lib.dp_encoder_workspace_bytes(C.byref(self.cfg))
         if self.save_bytes == 0 or self.ws_bytes == 0:
             _lib.check(-1, "dp_encoder_save_bytes / dp_encoder_workspace_bytes")
-        self.workspace = torch.empty(self.ws_bytes, device=device, dtype=torch.uint8)
+        # zero-filled ONCE: the persistent level-0 kernel's barrier block (start of the workspace) must be zero on first
+        # use and cleans up after itself on every launch (diffpool_hip.h, dp_encoder_workspace_bytes)
+        self.workspace = torch.zeros(self.ws_bytes, device=device, dtype=torch.uint8)
         self._eval_save = None
         self.prezero_owner = None
         self.device = device

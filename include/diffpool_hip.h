@@ -292,6 +292,10 @@ typedef struct {
 
 size_t dp_sizeof_encoder_cfg(void); /* sizeof(dp_encoder_cfg): lets a binding check its struct layout */
 size_t dp_encoder_save_bytes(const dp_encoder_cfg* cfg);
+/* The workspace of the model-level calls must be ZERO-FILLED ONCE after it is allocated (before its first use with
+ * this cfg) and then left alone between calls: its first block holds the barrier state of the persistent level-0
+ * kernel, which every launch leaves clean (also a launch whose barrier gave up).  A workspace with garbage there makes
+ * the first forward time out: DP_DEVERR_BARRIER on the next entry, NaN logits, never a hang. */
 size_t dp_encoder_workspace_bytes(const dp_encoder_cfg* cfg);
 
 /* Where one saved activation of pooling level `level` sits inside the `save` buffer after dp_encoder_forward: the

@@ -5,8 +5,8 @@ collective on over the single rank.  Executes, on the real RCCL backend:
   1. the flat-parameter broadcast and the gradient all-reduce with ReduceOp.AVG;
   2. the sync-BN exchange through the library's callback (dist.all_gather_into_tensor) and the link-normaliser
      all-reduce — the step must equal the oracle on the batch (one rank: global statistics == local statistics);
-  3. collective_capture_works (a captured + replayed all-reduce on a throw-away communicator);
-  4. a whole step — forward, loss, backward and the gradient all-reduce — captured into ONE hipGraph; replay must
+  4. collective_capture_works (a captured + replayed all-reduce on a throw-away communicator), run last;
+  3. a whole step — forward, loss, backward and the gradient all-reduce — captured into ONE hipGraph; replay must
      reproduce the eager step (every tensor except `*.bias`, whose float atomics differ in the last place between any
      two runs).  Mode `local` (argv[1], default): local BatchNorm statistics, the captured collective is the gradient
      all-reduce — bench.py's N > 1 configuration.  Mode `sync`: sync-BN, the eight all-gathers are captured too.
@@ -14,6 +14,7 @@ collective on over the single rank.  Executes, on the real RCCL backend:
 It is a one-rank run: it proves the calls execute and compose with graph capture on this runtime, not that two ranks
 agree (at one rank RCCL short-cuts an in-place all-reduce to nothing and an all-gather to a device copy).  Any RCCL
 failure is printed as `RCCL-ERROR: <text>` and the process exits non-zero; nothing is retried."""
+import faulthandler
 import os
 import sys
 import traceback
@@ -26,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    faulthandler.enable()          # a host crash inside the runtime still names the Python frame it came from
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     mode = sys.argv[1] if len(sys.argv) > 1 else "local"
@@ -80,12 +82,7 @@ def main():
     print("eager RCCL step (AVG all-reduce, all_gather_into_tensor x %d, link-norm all-reduce) equals the oracle"
           % n_calls, flush=True)
 
-    # ---- 3: a captured collective on a throw-away communicator
-    ok = collective_capture_works(device, 1, 0)
-    print(f"collective_capture_works -> {ok}", flush=True)
-    assert ok, "this runtime did not capture + replay an RCCL all-reduce"
-
-    # ---- 4: the whole step, collectives included, in one hipGraph
+    # ---- 3: the whole step, collectives included, in one hipGraph
     side = torch.cuda.Stream(device)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -111,6 +108,14 @@ def main():
         else:
             torch.testing.assert_close(p.grad, eager[k], rtol=0, atol=0, msg=lambda m, k=k: f"{k}: {m}")
     print(f"captured step ({mode} BatchNorm) with the RCCL collectives inside replays the eager step", flush=True)
+    # ---- 4: a captured collective on a throw-away communicator (bench.py's probe).  Run LAST: at one rank RCCL
+    # short-cuts the in-place all-reduce to nothing, the probe's graph is EMPTY, and a step captured after an empty
+    # graph crashed capture_end on this runtime (round 3, tools/rccl_capture_probe.py: every other order and capture
+    # mode passes) — with two or more ranks the probe's graph holds the collective's kernel
+    ok = collective_capture_works(device, 1, 0)
+    print(f"collective_capture_works -> {ok}", flush=True)
+    assert ok, "this runtime did not capture + replay an RCCL all-reduce"
+
     dist.destroy_process_group()
     print(f"RCCL world-1 run complete ({mode})", flush=True)
 
