@@ -422,8 +422,8 @@ struct Level0Fwd {
     int pk_ld;
     int* pk_flag;                  // 256-byte block: word 0 = "some entry is not bf16-exact", rest zero
     // exchange scratch (workspace)
-    unsigned short* vs;            // 3-plane split of the current aggregation operand
-    float* part;                   // [B, N, G, 2]
+    unsigned short* vs;            // level0_vs_elems(): the 3-plane split operand of every aggregation pass (write-once regions)
+    float* part;                   // level0_part_floats(): [L - 1][B, N, G, 2]
     float* xpart;                  // [B, T, epad] partial X' | A'
     float* mpart;                  // [B, T, rw, 2] partial (max, row)
     int* bar;                      // level0_bar_ints(B) ints, zero on first use, self-cleaning afterwards
@@ -434,6 +434,8 @@ struct Level0Fwd {
 bool level0_persistent_ok(const Level0Fwd& a);
 size_t level0_bar_ints(int B);
 size_t level0_xpart_floats(const Level0Fwd& a);
+size_t level0_vs_elems(const Level0Fwd& a);
+size_t level0_part_floats(const Level0Fwd& a);
 size_t level0_mpart_floats(const Level0Fwd& a);
 const int* level0_error_word(const int* bar);        // device word the head launch checks (ypred = NaN when set)
 void level0_forward(Seq& q, const Level0Fwd& a);

@@ -68,7 +68,7 @@ constexpr float L0_BN_EPS = 1e-5f;
 constexpr int L0_SPIN_LIMIT = 1 << 22;
 
 // barrier block (ints; every word that is polled or added to sits on a 64-byte line of its own)
-constexpr int BAR_GCOUNT = 0, BAR_GGEN = 16, BAR_DONE = 32, BAR_GFLAG = 48, BAR_ERR = 64, BAR_GRAPH0 = 128;
+constexpr int BAR_GCOUNT = 0, BAR_DONE = 32, BAR_GFLAG = 48, BAR_ERR = 64, BAR_GRAPH0 = 128;
 constexpr int BAR_GSTRIDE = 48;       // per graph: +0 count, +16 generation, +32 "adjacency not bf16-exact"
 
 // ---- write-through / L1-bypassing access to what other workgroups of this launch write or read
@@ -97,6 +97,7 @@ struct L0Args {
     int K8;                        // k8 groups of the split operand: ceil(N / 32) * 4
     int steps;                     // 32-deep k-steps: ceil(N / 32)
     int epad;                      // K*D + K*K padded to a multiple of 4
+    long vs_off[DP_MAX_LAYERS + 1]; // element offset of pass p's region in f.vs (passes 0..L-1: the layers' operands, L: S)
     int lds_act[2];                // float offsets of the activation rows [RB][ldz[g]] in LDS
     int lds_scr;                   // float offset of the scratch region
     int scr_floats;
@@ -153,43 +154,35 @@ __device__ inline void l0_mma(const float* A, int lda, const float* B, int ldb, 
 }
 
 // ---- barriers.  Every thread calls; returns false once a wait of this workgroup has given up (sticky).
+// Counters only ever grow inside a launch (the last workgroup to FINISH clears them): the e-th graph barrier of a
+// launch waits for the graph's counter to reach e * T; the e-th grid barrier adds the graph's last arriver to the global
+// counter and waits for e * B there.  `epoch` = {graph arrivals so far / T, grid barriers so far}, kept by the caller.
+struct L0Epoch {
+    int graph, grid;
+};
 template <bool GRID>
-__device__ inline bool l0_barrier(const L0Args& a, int b, int* sflag /*LDS: [0] ok, [1] failed (sticky)*/) {
+__device__ inline bool l0_barrier(const L0Args& a, int b, int* sflag /*LDS: [0] ok, [1] failed (sticky)*/, L0Epoch& ep) {
+    ep.graph += 1;
+    if (GRID) ep.grid += 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores are acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
         int ok = sflag[1] ? 0 : 1;
         int* gc = a.f.bar + BAR_GRAPH0 + b * BAR_GSTRIDE;
-        int* pollw = GRID ? a.f.bar + BAR_GGEN : gc + 16;
-        const int my_gen = ag_ld(pollw);                   // read BEFORE arriving
+        int* pollw = GRID ? a.f.bar + BAR_GCOUNT : gc;
+        const int target = (GRID ? ep.grid * a.f.B : ep.graph * a.T) + a.target_bias;
         const int old = ag_add(gc, 1);
-        bool released = false;
-        if (old == a.T - 1 + a.target_bias) {              // last of this graph
-            ag_st(gc, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (GRID) {
-                const int o2 = ag_add(a.f.bar + BAR_GCOUNT, 1);
-                if (o2 == a.f.B - 1) {
-                    ag_st(a.f.bar + BAR_GCOUNT, 0);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    ag_add(pollw, 1);
-                    released = true;
-                }
-            } else {
-                ag_add(pollw, 1);
-                released = true;
-            }
-        }
-        if (!released && ok) {
+        if (GRID && old + 1 == ep.graph * a.T) ag_add(a.f.bar + BAR_GCOUNT, 1);   // last of this graph
+        if (ok) {
             int it = 0;
-            while (ag_ld(pollw) == my_gen) {
+            while (ag_ld(pollw) < target) {
                 if (++it > a.spin_limit) {
                     ok = 0;
                     ag_st(a.f.bar + BAR_ERR, 1);
                     dev_err_raise(a.dev_err, DP_DEVERR_BARRIER);
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
         }
         sflag[0] = ok;
@@ -197,6 +190,31 @@ __device__ inline bool l0_barrier(const L0Args& a, int b, int* sflag /*LDS: [0] 
     }
     __syncthreads();
     return sflag[0] != 0;
+}
+
+// Bulk copy global -> LDS of `count` floats (4-byte aligned source): every thread asks for all its 16-byte quads before
+// it writes any (one memory round trip for the whole region, not one per loop iteration).  QN quads per thread at most
+// (count <= QN * 4 * 512); the <= 3 floats past the last whole quad go one by one.  zero_to: LDS floats [count, zero_to)
+// are cleared.
+template <int QN>
+__device__ __forceinline__ void l0_copy_in(float* dst, const float* src, int count, int zero_to = 0) {
+    const int nq = count >> 2;
+    float tail = 0.f;
+    const int te = (nq << 2) + (int)threadIdx.x;
+    if (te < count) tail = src[te];
+    for (int base = 0; base < nq; base += QN * L0_NT) {
+        f32x4_u q[QN];
+#pragma unroll
+        for (int u = 0; u < QN; ++u)
+            q[u] = *reinterpret_cast<const f32x4_u*>(src + 4 * min(base + u * L0_NT + (int)threadIdx.x, nq - 1));
+#pragma unroll
+        for (int u = 0; u < QN; ++u) {
+            const int e4 = base + u * L0_NT + (int)threadIdx.x;
+            if (e4 < nq) *reinterpret_cast<f32x4*>(dst + 4 * e4) = q[u];        // (dst is 16-byte aligned)
+        }
+    }
+    if (te < count) dst[te] = tail;
+    for (int e = count + (int)threadIdx.x; e < zero_to; e += L0_NT) dst[e] = 0.f;
 }
 
 // ---- the exact 3-plane bf16 split of PT [rows][ct] (LDS) into the graph's Vs block (dp_agg.hip layout
@@ -228,28 +246,36 @@ __device__ inline void l0_write_split(ScBuf vsb, const float* PT, int ct, int CT
 // Wave (kh = wave & 3, ch = wave >> 2): k-steps kh, kh + 4, ...; column tiles cb0 .. cb0 + CTH - 1 (clamped duplicates
 // beyond the operand's last tile: the caller ignores them).
 template <int MI, int CTH>
-__device__ __forceinline__ void l0_agg_bf16(const unsigned short* Alds, int ldp, ScBuf vsb, int CTt, int K8, int steps,
-                                            int cb0, f32x4 (&acc)[MI][CTH]) {
+__device__ __forceinline__ void l0_agg_bf16(const unsigned short* Alds, int ldp, const unsigned short* vsp, int CTt, int K8,
+                                            int steps, int rot, int cb0, f32x4 (&acc)[MI][CTH]) {
     const int lane = threadIdx.x & 63;
     const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
     const int l15 = lane & 15, kq = lane >> 4;
     s16x8 f0[3][CTH], f1[3][CTH];
+    // The blocks of a graph walk the k-steps from different starting points (`rot`): the operand was just written
+    // through to memory, so the first block to touch a line pays the miss and the others find it in the XCD's L2 —
+    // started together on the same lines, every block would sit at the per-CU miss rate (~10 B / cycle) for the whole
+    // operand.  (A k-step is a term of the sum: any order gives the same exact products, summed in a fixed order per block.)
+    auto eff = [&](int step) {
+        const int s2 = min(step, steps - 1) + rot;
+        return s2 >= steps ? s2 - steps : s2;
+    };
     auto load_b = [&](int step, s16x8 (&dst)[3][CTH]) {
-        const int st = min(step, steps - 1);
+        const int st = eff(step);
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int cbi = 0; cbi < CTH; ++cbi) {
                 const int cb = min(cb0 + cbi, CTt - 1);
                 const long o = ((((long)p * CTt + cb) * K8 + st * 4 + kq) * 16 + l15) * 8;
-                dst[p][cbi] = __builtin_bit_cast(s16x8, sc_ld16(vsb, (unsigned)(o * 2)));
+                dst[p][cbi] = *reinterpret_cast<const s16x8*>(vsp + o);
             }
     };
     auto mma = [&](int step, const s16x8 (&bf)[3][CTH]) {
         s16x8 av[MI];
 #pragma unroll
         for (int rb = 0; rb < MI; ++rb)
-            av[rb] = *reinterpret_cast<const s16x8*>(Alds + (rb * 16 + l15) * ldp + step * 32 + kq * 8);
+            av[rb] = *reinterpret_cast<const s16x8*>(Alds + (rb * 16 + l15) * ldp + eff(step) * 32 + kq * 8);
 #pragma unroll
         for (int p = 2; p >= 0; --p)          // lo, mid, hi: small terms first
 #pragma unroll
@@ -260,14 +286,30 @@ __device__ __forceinline__ void l0_agg_bf16(const unsigned short* Alds, int ldp,
                                                                            __builtin_bit_cast(bf16x8, bf[p][cbi]),
                                                                            acc[rb][cbi], 0, 0, 0);
     };
-    load_b(kh, f0);
-    load_b(kh + 4, f1);
-    for (int step = kh; step < steps; step += 8) {
-        mma(step, f0);
-        if (step + 4 < steps) {
-            load_b(step + 8, f0);
-            mma(step + 4, f1);
-            load_b(step + 12, f1);
+    if constexpr (CTH <= 2) {
+        // narrow halves: the fragments of FOUR k-steps (all of a DD-sized graph's share) are requested before the first
+        // multiply — the pass is a chain of memory round trips, not of MFMAs
+        s16x8 f2[3][CTH], f3[3][CTH];
+        for (int step = kh; step < steps; step += 16) {
+            load_b(step, f0);
+            load_b(step + 4, f1);
+            load_b(step + 8, f2);
+            load_b(step + 12, f3);
+            mma(step, f0);
+            if (step + 4 < steps) mma(step + 4, f1);
+            if (step + 8 < steps) mma(step + 8, f2);
+            if (step + 12 < steps) mma(step + 12, f3);
+        }
+    } else {
+        load_b(kh, f0);
+        load_b(kh + 4, f1);
+        for (int step = kh; step < steps; step += 8) {
+            mma(step, f0);
+            if (step + 4 < steps) {
+                load_b(step + 8, f0);
+                mma(step + 4, f1);
+                load_b(step + 12, f1);
+            }
         }
     }
 }
@@ -276,8 +318,8 @@ __device__ __forceinline__ void l0_agg_bf16(const unsigned short* Alds, int ldp,
 // in global memory (element (i, k) at Ag[i * rs + k * ks]: rs = N, ks = 1 for A; rs = 1, ks = N for A^T), V rebuilt
 // exactly from its planes (hi + mid + lo == v).  Slow; only weighted adjacency ever comes here.
 template <int MI, int CTH>
-__device__ __forceinline__ void l0_agg_f32(const float* Ag, long rs, long ks, int nrows, int N, ScBuf vsb, int CTt, int K8,
-                                           int steps, int cb0, f32x4 (&acc)[MI][CTH]) {
+__device__ __forceinline__ void l0_agg_f32(const float* Ag, long rs, long ks, int nrows, int N, const unsigned short* vsp,
+                                           int CTt, int K8, int steps, int cb0, f32x4 (&acc)[MI][CTH]) {
     const int lane = threadIdx.x & 63;
     const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -290,7 +332,7 @@ __device__ __forceinline__ void l0_agg_f32(const float* Ag, long rs, long ks, in
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const long o = ((((long)p * CTt + cb) * K8 + step * 4 + kq) * 16 + l15) * 8;
-                pl3[p] = __builtin_bit_cast(u16x8, sc_ld16(vsb, (unsigned)(o * 2)));
+                pl3[p] = *reinterpret_cast<const u16x8*>(vsp + o);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -319,7 +361,8 @@ __device__ __forceinline__ void l0_agg_f32(const float* Ag, long rs, long ks, in
 // One aggregation pass into the k-quarter slots red[kh][RB][ctp] (the caller sums the four quarters).
 template <int MI, int CTH>
 __device__ __forceinline__ void l0_aggregate_pass(const L0Args& a, const unsigned short* Alds, bool exact, const float* Ag,
-                                                  long rs, long ks, int nrows, ScBuf vsb, int CTt, float* red, int ctp) {
+                                                  long rs, long ks, int nrows, const unsigned short* vsb, int CTt, float* red,
+                                                  int ctp, int rot) {
     constexpr int RB = MI * 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -333,7 +376,7 @@ __device__ __forceinline__ void l0_aggregate_pass(const L0Args& a, const unsigne
 #pragma unroll
         for (int j = 0; j < CTH; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (ncb > 0) {
-        if (exact) l0_agg_bf16<MI, CTH>(Alds, a.ldp, vsb, CTt, a.K8, a.steps, cb0, acc);
+        if (exact) l0_agg_bf16<MI, CTH>(Alds, a.ldp, vsb, CTt, a.K8, a.steps, rot, cb0, acc);
         else l0_agg_f32<MI, CTH>(Ag, rs, ks, nrows, a.f.N, vsb, CTt, a.K8, a.steps, cb0, acc);
     }
 #pragma unroll
@@ -348,14 +391,14 @@ __device__ __forceinline__ void l0_aggregate_pass(const L0Args& a, const unsigne
 }
 template <int MI>
 __device__ __forceinline__ void l0_aggregate(const L0Args& a, const unsigned short* Alds, bool exact, const float* Ag, long rs,
-                                             long ks, int nrows, ScBuf vsb, int CTt, float* red, int ctp) {
+                                             long ks, int nrows, const unsigned short* vsb, int CTt, float* red, int ctp, int rot) {
     const int cth = (CTt + 1) >> 1;
-    if (cth <= 1) l0_aggregate_pass<MI, 1>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp);
-    else if (cth == 2) l0_aggregate_pass<MI, 2>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp);
-    else l0_aggregate_pass<MI, 3>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp);
+    if (cth <= 1) l0_aggregate_pass<MI, 1>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp, rot);
+    else if (cth == 2) l0_aggregate_pass<MI, 2>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp, rot);
+    else l0_aggregate_pass<MI, 3>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp, rot);
 }
 
-// 16-byte-quad staging of RB rows of a bf16 operand [*, ld] into the LDS adjacency block (sc1 loads; columns >= ld and
+// 16-byte-quad staging of RB rows of a bf16 operand [*, ld] into the LDS adjacency block (columns >= ld and
 // rows >= nrows become zeros up to the k-step padding): issue() asks for everything, commit() writes LDS.
 template <int MI>
 struct L0RowStage {
@@ -363,14 +406,14 @@ struct L0RowStage {
     u32x4 q[NQ];
 };
 template <int MI>
-__device__ __forceinline__ void l0_stage_issue(L0RowStage<MI>& s, ScBuf buf, long row0_elems, int ld, int nrows, int seg) {
+__device__ __forceinline__ void l0_stage_issue(L0RowStage<MI>& s, const unsigned short* rows, int ld, int nrows, int seg) {
     const int tq = threadIdx.x & 63, tr = threadIdx.x >> 6;
     const int c8 = seg * 64 + tq;
 #pragma unroll
     for (int u = 0; u < L0RowStage<MI>::NQ; ++u) {
         const int row = min(tr + 8 * u, max(nrows - 1, 0));
         const int cc = min(c8 * 8, ld - 8);
-        s.q[u] = sc_ld16(buf, (unsigned)((row0_elems + (long)row * ld + cc) * 2));
+        s.q[u] = *reinterpret_cast<const u32x4*>(rows + (long)row * ld + cc);
     }
 }
 template <int MI>
@@ -406,38 +449,42 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
     const int r0 = rb * RB;
     const int nrows = min(RB, N - r0);                      // valid rows of this block (>= 1)
     const int nb = f.num_nodes ? min(f.num_nodes[b], N) : N;
+    const int rot = (rb * 4) % a.steps;                     // this block's starting k-step in the aggregations
     L0_STAMP(0);
 
     unsigned short* Alds = reinterpret_cast<unsigned short*>(lds);              // [RB][ldp] bf16
     float* ACT0 = lds + a.lds_act[0];                      // [RB][ldz[0]]  this block's rows of Ze
     float* ACT1 = lds + a.lds_act[1];                      // [RB][ldz[1]]  ... of Za
     float* SCR = lds + a.lds_scr;
-    int* sflag = reinterpret_cast<int*>(lds + a.lds_scr + a.scr_floats);       // [0] ok, [1] failed, [2] block flag
+    float* BIAS = lds + a.lds_scr + a.scr_floats;          // every layer's biases [l][g][64], then assign_pred's [64]
+    int* sflag = reinterpret_cast<int*>(BIAS + (2 * DP_MAX_LAYERS + 1) * 64);   // [0] ok, [1] failed, [2] block flag, [3] last
     if (tid < 4) sflag[tid] = 0;
-    __syncthreads();
+    L0Epoch ep{0, 0};
 
-    // the graph's block of the split operand: laid out per pass for that pass's column-tile count (dp_agg.hip layout)
-    auto vs_of = [&](int CTt) {
-        return sc_buf(f.vs + (long)b * 3 * CTt * a.K8 * 128, (size_t)3 * CTt * a.K8 * 128 * 2);
+    // Exchange buffers are WRITE-ONCE per launch (one region per pass): a reader can only ever fetch a line after its
+    // writers are done, so no cache of this launch can hold a stale copy and the reads are ordinary cached loads (the
+    // blocks of a graph share the XCD's L2); the writes are write-through (sc1) and drained before the barrier.
+    auto vs_wr = [&](int pass, int CTt) {
+        return sc_buf(f.vs + a.vs_off[pass] + (long)b * 3 * CTt * a.K8 * 128, (size_t)3 * CTt * a.K8 * 128 * 2);
     };
-    const ScBuf partb = sc_buf(f.part, (size_t)f.B * N * G * 2 * sizeof(float));
+    auto vs_rd = [&](int pass, int CTt) { return f.vs + a.vs_off[pass] + (long)b * 3 * CTt * a.K8 * 128; };
 
     // ------------------------------------------------------------------ phase 0
-    // side jobs: clear the backward accumulators, the pooled level's barrier block, last call's error word
-    if (f.zero_p) {
-        uint4* zp = reinterpret_cast<uint4*>(f.zero_p);
-        const long nwg = gridDim.x, per = (a.zero_n16 + nwg - 1) / nwg;
-        const long end = min(a.zero_n16, ((long)wid + 1) * per);
-        for (long i = (long)wid * per + tid; i < end; i += L0_NT) zp[i] = make_uint4(0, 0, 0, 0);
-    }
+    // side jobs: the pooled level's barrier block, last call's error word
     if (wid == 0) {
         if (f.next_bar && tid < 64) f.next_bar[tid] = 0;
         if (tid == 64) ag_st(f.bar + BAR_ERR, 0);
     }
     L0_STAMP(1);
-    const int din0[2] = {f.st[0].dims[0], G == 2 ? f.st[1].dims[0] : 0};
-    // (a) my rows of the fp32 adjacency -> bf16: LDS block, packed A rows, exactness
+    const int din0_0 = f.st[0].dims[0], din0_1 = G == 2 ? f.st[1].dims[0] : 0;
+    // (a) my rows of the fp32 adjacency -> bf16: LDS block, packed A rows, exactness.  The layer-0 inputs, weights and
+    // every bias are asked for right behind the adjacency quads, so they arrive under the same burst.
     bool bad = false;
+    float* const X0s0 = SCR;
+    float* const X0s1 = X0s0 + RB * din0_0;
+    float* const W0s0 = X0s1 + RB * din0_1;
+    float* const W0s1 = W0s0 + ((din0_0 * f.st[0].dims[1] + 3) & ~3);
+    float* const PT = W0s1 + (G == 2 ? ((din0_1 * f.st[1].dims[1] + 3) & ~3) : 0);
     {
         const float* Ab = f.A + ((long)b * N + r0) * N;
         unsigned short* Pb = f.pkA + ((long)b * N + r0) * f.pk_ld;
@@ -449,6 +496,26 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
 #pragma unroll
             for (int u = 0; u < 4 * MI; ++u)
                 v[u] = *reinterpret_cast<const f32x4_u*>(Ab + (long)min(tr + 4 * u, nrows - 1) * N + min(c, N - 4));
+            if (seg == 0) {
+                l0_copy_in<4>(X0s0, f.x0[0] + ((long)b * N + r0) * din0_0, nrows * din0_0, RB * din0_0);
+                l0_copy_in<4>(W0s0, f.params + f.st[0].w_off[0], din0_0 * f.st[0].dims[1]);
+                if (G == 2) {
+                    l0_copy_in<4>(X0s1, f.x0[1] + ((long)b * N + r0) * din0_1, nrows * din0_1, RB * din0_1);
+                    l0_copy_in<4>(W0s1, f.params + f.st[1].w_off[0], din0_1 * f.st[1].dims[1]);
+                }
+                // biases: one 64-float slot per (layer, stack), zeros where a layer has none
+                for (int e = tid; e < (2 * L + 1) * 64; e += L0_NT) {
+                    const int slot = e >> 6, c = e & 63;
+                    float v0 = 0.f;
+                    if (slot < 2 * L) {
+                        const int l = slot >> 1, g = slot & 1;
+                        if (g < G && f.st[g].b_off[l] >= 0 && c < f.st[g].dims[l + 1]) v0 = f.params[f.st[g].b_off[l] + c];
+                    } else if (G == 2 && f.bp_off >= 0 && c < f.K) {
+                        v0 = f.params[f.bp_off + c];
+                    }
+                    BIAS[(slot < 2 * L ? slot : 2 * DP_MAX_LAYERS) * 64 + c] = v0;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 4 * MI; ++u) {
                 const int row = tr + 4 * u;
@@ -466,32 +533,14 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         }
     }
     L0_STAMP(2);
-    if (__any(bad) && lane == 0) sflag[2] = 1;
-    // (b) layer-0 inputs and weights -> LDS scratch:  X_g [RB][din], W_g [din][dout]
-    float* X0s[2];
-    float* W0s[2];
-    float* PT;
-    {
-        float* p = SCR;
-        for (int g = 0; g < G; ++g) {
-            X0s[g] = p;
-            p += RB * din0[g];
-        }
-        for (int g = 0; g < G; ++g) {
-            W0s[g] = p;
-            p += din0[g] * f.st[g].dims[1];
-        }
-        PT = p;
-        for (int g = 0; g < G; ++g) {
-            {
-                const float* xg = f.x0[g] + ((long)b * N + r0) * din0[g];
-                const int cnt = nrows * din0[g];
-                for (int e = tid; e < RB * din0[g]; e += L0_NT) X0s[g][e] = e < cnt ? xg[min(e, cnt - 1)] : 0.f;
-            }
-            const float* wg = f.params + f.st[g].w_off[0];
-            for (int e = tid; e < din0[g] * f.st[g].dims[1]; e += L0_NT) W0s[g][e] = wg[e];
-        }
+    // side job: clear the backward accumulators (behind the adjacency burst: the stores drain under the phases below)
+    if (f.zero_p) {
+        uint4* zp = reinterpret_cast<uint4*>(f.zero_p);
+        const long nwg = gridDim.x, per = (a.zero_n16 + nwg - 1) / nwg;
+        const long end = min(a.zero_n16, ((long)wid + 1) * per);
+        for (long i = (long)wid * per + tid; i < end; i += L0_NT) zp[i] = make_uint4(0, 0, 0, 0);
     }
+    if (__any(bad) && lane == 0) sflag[2] = 1;
     __syncthreads();
     L0_STAMP(3);
     const bool blk_bad = sflag[2] != 0;
@@ -518,19 +567,19 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
     int ct = f.st[0].dims[1] + (G == 2 ? f.st[1].dims[1] : 0);
     for (int g = 0; g < G; ++g) {
         const int dout = f.st[g].dims[1], c0 = g ? f.st[0].dims[1] : 0;
-        l0_mma<false, false>(X0s[g], din0[g], W0s[g], dout, RB, dout, din0[g],
+        l0_mma<false, false>(g ? X0s1 : X0s0, g ? din0_1 : din0_0, g ? W0s1 : W0s0, dout, RB, dout, g ? din0_1 : din0_0,
                              [&](int r, int c, float v) { PT[r * ct + c0 + c] = v; }, g * 3);
     }
     __syncthreads();
     L0_STAMP(5);
+    const int k8_0 = r0 / 8;
+    const int nk8 = min(rb == a.T - 1 ? a.K8 - k8_0 : RB / 8, a.K8 - k8_0);
     {
         const int CTt = (ct + 15) / 16;
-        const int k8_0 = r0 / 8;
-        const int nk8 = min(rb == a.T - 1 ? a.K8 - k8_0 : RB / 8, a.K8 - k8_0);
-        l0_write_split(vs_of(CTt), PT, ct, CTt, a.K8, k8_0, nk8, nrows);
+        l0_write_split(vs_wr(0, CTt), PT, ct, CTt, a.K8, k8_0, nk8, nrows);
     }
     L0_STAMP(6);
-    bool ok = l0_barrier<false>(a, b, sflag);
+    bool ok = l0_barrier<false>(a, b, sflag, ep);
     L0_STAMP(7);
     const bool exact = ag_ld(f.bar + BAR_GRAPH0 + b * BAR_GSTRIDE + 32) == 0;
     const float* Arows = f.A + ((long)b * N + r0) * N;             // fp32 fallback operands
@@ -540,27 +589,31 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
     constexpr int ITEMS = (RB * 2 + L0_TEAMS - 1) / L0_TEAMS;      // (row, group) items per team
     for (int l = 0; l < L; ++l) {
         const bool last = l == L - 1;
-        const int w[2] = {f.st[0].dims[l + 1], G == 2 ? f.st[1].dims[l + 1] : 0};
-        const int c0g[2] = {0, w[0]};
+        const int w0 = f.st[0].dims[l + 1], w1 = G == 2 ? f.st[1].dims[l + 1] : 0;
+        const int wmax = max(w0, w1);
         const int CTt = (ct + 15) / 16;
         const int ctp = CTt * 16 + 1;
         float* red = SCR;
         // U = A_rows . P_l   (four k-quarter partials)
-        l0_aggregate<MI>(a, Alds, exact, Arows, N, 1, nrows, vs_of(CTt), CTt, red, ctp);
+        l0_aggregate<MI>(a, Alds, exact, Arows, N, 1, nrows, vs_rd(l, CTt), CTt, red, ctp, rot);
         L0_STAMP(8 + 8 * l);
         // next layer's weights go to LDS behind the reduce slots now: their latency hides under the tail
-        int wn[2] = {0, 0};
-        float* Wn[2] = {red + 4 * RB * ctp, nullptr};
+        int wn0 = 0, wn1 = 0;
+        float* const Wn0 = red + 4 * RB * ctp;
         if (!last) {
-            for (int g = 0; g < G; ++g) wn[g] = f.st[g].dims[l + 1] * f.st[g].dims[l + 2];
-            Wn[1] = Wn[0] + wn[0];
-            for (int e = tid; e < wn[0] + wn[1]; e += L0_NT)
-                Wn[0][e] = e < wn[0] ? f.params[f.st[0].w_off[l + 1] + e] : f.params[f.st[1].w_off[l + 1] + e - wn[0]];
+            wn0 = f.st[0].dims[l + 1] * f.st[0].dims[l + 2];
+            wn1 = G == 2 ? f.st[1].dims[l + 1] * f.st[1].dims[l + 2] : 0;
+        }
+        float* const Wn1 = Wn0 + ((wn0 + 3) & ~3);
+        if (!last) {
+            l0_copy_in<4>(Wn0, f.params + f.st[0].w_off[l + 1], wn0);
+            if (G == 2) l0_copy_in<4>(Wn1, f.params + f.st[1].w_off[l + 1], wn1);
         }
         __syncthreads();
         L0_STAMP(9 + 8 * l);
         // tail: + bias, l2-normalise, save, BatchNorm partials — one 16-lane team per (row, group); y also goes to the
         // layer's slice of the LDS activation rows (BatchNorm rewrites it in place after the exchange)
+        const ScBuf partw = sc_buf(f.part + (long)l * f.B * N * G * 2, (size_t)f.B * N * G * 2 * sizeof(float));
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             float yv[L0_NK];
@@ -568,31 +621,36 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
             const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
             const bool on = it < RB * G && r < nrows;
             const long row = (long)b * N + min(r0 + r, N - 1);
-            const int wg = w[g];
-            const float* bias = f.st[g].b_off[l] >= 0 ? f.params + f.st[g].b_off[l] : nullptr;
+            const int wg = g ? w1 : w0, c0gg = g ? w0 : 0;
+            const float* bias = BIAS + (2 * l + g) * 64;
             float ss = 0.f;
 #pragma unroll
             for (int k = 0; k < L0_NK; ++k) {
-                const int c = min(tl + 16 * k, wg - 1);
-                const int o = r * ctp + c0g[g] + c;
-                float v = (red[o] + red[RB * ctp + o]) + (red[2 * RB * ctp + o] + red[3 * RB * ctp + o]);
-                if (bias) v += bias[c];
-                v = tl + 16 * k < wg ? v : 0.f;
-                yv[k] = v;
-                ss += v * v;
+                yv[k] = 0.f;
+                if (16 * k < wmax) {                       // (uniform: no lane of the workgroup has a column there)
+                    const int c = min(tl + 16 * k, wg - 1);
+                    const int o = r * ctp + c0gg + c;
+                    float v = ((red[o] + red[RB * ctp + o]) + (red[2 * RB * ctp + o] + red[3 * RB * ctp + o])) + bias[c];
+                    v = tl + 16 * k < wg ? v : 0.f;
+                    yv[k] = v;
+                    ss += v * v;
+                }
             }
             ss = row16_sum(ss);
-            const float inv = 1.f / fmaxf(sqrtf(ss), L0_L2_EPS);
+            // x / max(||x||, eps)  (F.normalize, encoders.py:972): v_rsq_f32 is within 1 ulp of 1 / sqrt
+            const float inv = ss > L0_L2_EPS * L0_L2_EPS ? __builtin_amdgcn_rsqf(ss) : 1.f / L0_L2_EPS;
             float s1 = 0.f;
-            float* yg = last ? f.Z[g] + row * f.ldz[g] + f.coff[g][l] : f.Y[l] + row * ct + c0g[g];
+            float* yg = last ? f.Z[g] + row * f.ldz[g] + f.coff[g][l] : f.Y[l] + row * ct + c0gg;
             float* act = (g ? ACT1 : ACT0) + r * f.ldz[g] + f.coff[g][l];
 #pragma unroll
             for (int k = 0; k < L0_NK; ++k) {
-                const int c = tl + 16 * k;
-                yv[k] *= inv;
-                if (on && c < wg) yg[c] = yv[k];
-                if (it < RB * G && c < wg) act[c] = r < nrows ? yv[k] : 0.f;
-                s1 += fmaxf(yv[k], 0.f);
+                if (16 * k < wmax) {
+                    const int c = tl + 16 * k;
+                    yv[k] *= inv;
+                    if (on && c < wg) yg[c] = yv[k];
+                    if (it < RB * G && c < wg) act[c] = r < nrows ? yv[k] : 0.f;
+                    s1 += fmaxf(yv[k], 0.f);
+                }
             }
             if (on && tl == 0) f.invn[l][row * G + g] = inv;
             if (!last && f.bn) {
@@ -601,67 +659,85 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
                 float m2 = 0.f;
 #pragma unroll
                 for (int k = 0; k < L0_NK; ++k) {
-                    const float v = (tl + 16 * k < wg) ? fmaxf(yv[k], 0.f) - mean : 0.f;
-                    m2 += v * v;
+                    if (16 * k < wmax) {
+                        const float v = (tl + 16 * k < wg) ? fmaxf(yv[k], 0.f) - mean : 0.f;
+                        m2 += v * v;
+                    }
                 }
                 m2 = row16_sum(m2);
-                if (on && tl == 0) {
-                    sc_stf(partb, (unsigned)(((row * G + g) * 2) * 4), mean);
-                    sc_stf(partb, (unsigned)(((row * G + g) * 2 + 1) * 4), m2);
+                if (on && tl == 0) {               // [node][group][graph][2]: a node's B pairs are contiguous for the reader
+                    const long po = ((((long)min(r0 + r, N - 1) * G + g) * f.B + b) * 2) * 4;
+                    sc_stf(partw, (unsigned)po, mean);
+                    sc_stf(partw, (unsigned)(po + 4), m2);
                 }
             }
         }
         L0_STAMP(10 + 8 * l);
         if (last) break;
         // ---- apply_bn: every graph's partials of my node indices (grid barrier), then x = (relu(y) - mu) * rstd
-        if (f.bn) ok = l0_barrier<true>(a, b, sflag) && ok;
+        if (f.bn) ok = l0_barrier<true>(a, b, sflag, ep) && ok;
         else __syncthreads();
         L0_STAMP(11 + 8 * l);
         const int ctn = f.st[0].dims[l + 2] + (G == 2 ? f.st[1].dims[l + 2] : 0);
-        float* PTn = Wn[0] + wn[0] + wn[1];                // behind the weights (which sit behind the reduce slots)
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int it = team + j * L0_TEAMS;
-            const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
-            const bool on = it < RB * G && r < nrows;
-            const int node = min(r0 + r, N - 1);
-            const long row = (long)b * N + node;
-            const int wg = w[g];
-            float mu = 0.f, rstd = 1.f;
+        float* PTn = Wn1 + ((wn1 + 3) & ~3);               // behind the weights (which sit behind the reduce slots)
+        {
+            // all the partials of all my items first (one round trip), then the combines
+            const float* partr = f.part + (long)l * f.B * N * G * 2;
+            float pm[ITEMS][L0_BPAIRS], pq[ITEMS][L0_BPAIRS];
             if (f.bn) {
-                float pm[L0_BPAIRS], pq[L0_BPAIRS];
 #pragma unroll
-                for (int u = 0; u < L0_BPAIRS; ++u) {
-                    const long o = ((((long)min(tl + 16 * u, f.B - 1) * N + node) * G + g) * 2) * 4;
-                    pm[u] = sc_ldf(partb, (unsigned)o);
-                    pq[u] = sc_ldf(partb, (unsigned)(o + 4));
-                }
-                float sm = 0.f;
+                for (int j = 0; j < ITEMS; ++j) {
+                    const int it = team + j * L0_TEAMS;
+                    const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+                    const int node = min(r0 + r, N - 1);
 #pragma unroll
-                for (int u = 0; u < L0_BPAIRS; ++u) sm += (tl + 16 * u < f.B) ? pm[u] : 0.f;
-                mu = row16_sum(sm) / (float)f.B;
-                float s2 = 0.f;
-#pragma unroll
-                for (int u = 0; u < L0_BPAIRS; ++u) {
-                    const float d = pm[u] - mu;
-                    s2 += (tl + 16 * u < f.B) ? pq[u] + (float)wg * d * d : 0.f;
-                }
-                const float var = row16_sum(s2) / ((float)f.B * (float)wg);
-                rstd = 1.0f / sqrtf(var + L0_BN_EPS);
-                if (!ok) mu = rstd = __builtin_nanf("");
-                if (on && b == 0 && tl == 0) {
-                    f.stats[l][((long)node * G + g) * 2] = mu;
-                    f.stats[l][((long)node * G + g) * 2 + 1] = rstd;
+                    for (int u = 0; u < L0_BPAIRS; ++u) {
+                        const float2 pr = *reinterpret_cast<const float2*>(
+                            partr + ((((long)node * G + g) * f.B) + min(tl + 16 * u, f.B - 1)) * 2);
+                        pm[j][u] = pr.x;
+                        pq[j][u] = pr.y;
+                    }
                 }
             }
-            float* xg = f.Z[g] + row * f.ldz[g] + f.coff[g][l];
-            float* act = (g ? ACT1 : ACT0) + r * f.ldz[g] + f.coff[g][l];
 #pragma unroll
-            for (int k = 0; k < L0_NK; ++k) {
-                const int c = tl + 16 * k;
-                const float xv = (fmaxf(act[min(c, wg - 1)], 0.f) - mu) * rstd;
-                if (on && c < wg) xg[c] = xv;
-                if (it < RB * G && c < wg) act[c] = r < nrows ? xv : 0.f;
+            for (int j = 0; j < ITEMS; ++j) {
+                const int it = team + j * L0_TEAMS;
+                const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+                const bool on = it < RB * G && r < nrows;
+                const int node = min(r0 + r, N - 1);
+                const long row = (long)b * N + node;
+                const int wg = g ? w1 : w0;
+                float mu = 0.f, rstd = 1.f;
+                if (f.bn) {
+                    float sm = 0.f;
+#pragma unroll
+                    for (int u = 0; u < L0_BPAIRS; ++u) sm += (tl + 16 * u < f.B) ? pm[j][u] : 0.f;
+                    mu = row16_sum(sm) / (float)f.B;
+                    float s2 = 0.f;
+#pragma unroll
+                    for (int u = 0; u < L0_BPAIRS; ++u) {
+                        const float d = pm[j][u] - mu;
+                        s2 += (tl + 16 * u < f.B) ? pq[j][u] + (float)wg * d * d : 0.f;
+                    }
+                    const float var = row16_sum(s2) / ((float)f.B * (float)wg);
+                    rstd = __builtin_amdgcn_rsqf(var + L0_BN_EPS);
+                    if (!ok) mu = rstd = __builtin_nanf("");
+                    if (on && b == 0 && tl == 0) {
+                        f.stats[l][((long)node * G + g) * 2] = mu;
+                        f.stats[l][((long)node * G + g) * 2 + 1] = rstd;
+                    }
+                }
+                float* xg = f.Z[g] + row * f.ldz[g] + f.coff[g][l];
+                float* act = (g ? ACT1 : ACT0) + r * f.ldz[g] + f.coff[g][l];
+#pragma unroll
+                for (int k = 0; k < L0_NK; ++k) {
+                    if (16 * k < wmax) {
+                        const int c = tl + 16 * k;
+                        const float xv = (fmaxf(act[min(c, wg - 1)], 0.f) - mu) * rstd;
+                        if (on && c < wg) xg[c] = xv;
+                        if (it < RB * G && c < wg) act[c] = r < nrows ? xv : 0.f;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -669,19 +745,17 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         // ---- P_{l+1} = [x_e W_e | x_a W_a] of my rows and its split
         for (int g = 0; g < G; ++g) {
             const int din = f.st[g].dims[l + 1], dout = f.st[g].dims[l + 2], c0 = g ? f.st[0].dims[l + 2] : 0;
-            l0_mma<false, false>((g ? ACT1 : ACT0) + f.coff[g][l], f.ldz[g], Wn[g], dout, RB, dout, din,
+            l0_mma<false, false>((g ? ACT1 : ACT0) + f.coff[g][l], f.ldz[g], g ? Wn1 : Wn0, dout, RB, dout, din,
                                  [&](int r, int c, float v) { PTn[r * ctn + c0 + c] = v; }, g * 3);
         }
         __syncthreads();
         L0_STAMP(13 + 8 * l);
         {
             const int CTn = (ctn + 15) / 16;
-            const int k8_0 = r0 / 8;
-            const int nk8 = min(rb == a.T - 1 ? a.K8 - k8_0 : RB / 8, a.K8 - k8_0);
-            l0_write_split(vs_of(CTn), PTn, ctn, CTn, a.K8, k8_0, nk8, nrows);
+            l0_write_split(vs_wr(l + 1, CTn), PTn, ctn, CTn, a.K8, k8_0, nk8, nrows);
         }
         L0_STAMP(14 + 8 * l);
-        ok = l0_barrier<false>(a, b, sflag) && ok;
+        ok = l0_barrier<false>(a, b, sflag, ep) && ok;
         L0_STAMP(15 + 8 * l);
         ct = ctn;
     }
@@ -696,16 +770,12 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         float* TL = SCR + 4 * RB * ctpk;                   // [RB][K]  T rows        (beyond the reduce slots of the A^T S pass)
         float* SL = TL + RB * K;                           // [RB][K]  logits, then S rows
         float* WP = SCR;                                   // [K][Da]  (the reduce area is free now)
-        {
-            const float* wp = f.params + f.wp_off;
-            for (int e = tid; e < K * Da; e += L0_NT) WP[e] = wp[e];
-        }
+        l0_copy_in<4>(WP, f.params + f.wp_off, K * Da);
         __syncthreads();
         L0_STAMP(40);
         {
-            const float* bp = f.bp_off >= 0 ? f.params + f.bp_off : nullptr;
-            l0_mma<false, true>(ACT1, Da, WP, Da, RB, K, Da,
-                                [&](int r, int c, float v) { SL[r * K + c] = bp ? v + bp[c] : v; });
+            const float* bp = BIAS + 2 * DP_MAX_LAYERS * 64;
+            l0_mma<false, true>(ACT1, Da, WP, Da, RB, K, Da, [&](int r, int c, float v) { SL[r * K + c] = v + bp[c]; });
         }
         __syncthreads();
         L0_STAMP(41);
@@ -743,31 +813,27 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         }
         __syncthreads();
         L0_STAMP(42);
-        {
-            const int k8_0 = r0 / 8;
-            const int nk8 = min(rb == a.T - 1 ? a.K8 - k8_0 : RB / 8, a.K8 - k8_0);
-            l0_write_split(vs_of(CTk), SL, K, CTk, a.K8, k8_0, nk8, nrows);
-        }
+        l0_write_split(vs_wr(L, CTk), SL, K, CTk, a.K8, k8_0, nk8, nrows);
         L0_STAMP(43);
-        // my rows of A^T replace my rows of A (every wave is past the last GraphConv pass): asked for in front of the
-        // barrier, written to LDS behind it
+        // my rows of A^T replace my rows of A (every wave is long past the last GraphConv pass; the strips were complete
+        // at barrier 0): ordinary loads, asked for in front of the barrier, written to LDS behind it
         {
             const int segs = (a.steps * 32 + 511) / 512;
-            const ScBuf atb = sc_buf(f.pkAt + (long)b * N * f.pk_ld, (size_t)N * f.pk_ld * 2);
+            const unsigned short* atp = f.pkAt + ((long)b * N + r0) * f.pk_ld;
             L0RowStage<MI> atq;
-            l0_stage_issue<MI>(atq, atb, (long)r0 * f.pk_ld, f.pk_ld, nrows, 0);
-            ok = l0_barrier<false>(a, b, sflag) && ok;
+            l0_stage_issue<MI>(atq, atp, f.pk_ld, nrows, 0);
+            ok = l0_barrier<false>(a, b, sflag, ep) && ok;
             L0_STAMP(44);
             l0_stage_commit<MI>(atq, Alds, a.ldp, f.pk_ld, nrows, 0);
             for (int seg = 1; seg < segs; ++seg) {
-                l0_stage_issue<MI>(atq, atb, (long)r0 * f.pk_ld, f.pk_ld, nrows, seg);
+                l0_stage_issue<MI>(atq, atp, f.pk_ld, nrows, seg);
                 l0_stage_commit<MI>(atq, Alds, a.ldp, f.pk_ld, nrows, seg);
             }
         }
         __syncthreads();
         L0_STAMP(45);
         // ------------------------------------------------------------------ T = A^T S (my rows), partial X', A'
-        l0_aggregate<MI>(a, Alds, exact, Acols, 1, N, nrows, vs_of(CTk), CTk, SCR, ctpk);
+        l0_aggregate<MI>(a, Alds, exact, Acols, 1, N, nrows, vs_rd(L, CTk), CTk, SCR, ctpk, rot);
         L0_STAMP(46);
         __syncthreads();
         L0_STAMP(47);
@@ -802,14 +868,39 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
     if (f.do_max) {
         const int nm = f.mask_readout ? max(min(nb - r0, nrows), 0) : nrows;   // rows that take part
         const ScBuf mpb = sc_buf(f.mpart + ((long)b * a.T + rb) * f.rw * 2, (size_t)f.rw * 2 * 4);
+        // (column, row group) per thread: eight groups of RB / 8 rows, merged in row order (strict >: lowest row wins ties)
+        float* MV = XP + a.epad;                           // [8][rw] best value, [8][rw] row (behind the partial products)
+        int* MI_ = reinterpret_cast<int*>(MV + 8 * f.rw);
+        constexpr int RG = RB / 8;
+        for (int c0 = 0; c0 < f.rw; c0 += 64) {
+            const int c = c0 + (tid & 63), grp = tid >> 6;
+            float best = -INFINITY;
+            int bi = -1;
+            if (c < f.rw) {
+#pragma unroll
+                for (int rr = 0; rr < RG; ++rr) {
+                    const int r = grp * RG + rr;
+                    const float v = ACT0[r * D + f.zoff + c];
+                    if (r < nm && v > best) {
+                        best = v;
+                        bi = r0 + r;
+                    }
+                }
+                MV[grp * f.rw + c] = best;
+                MI_[grp * f.rw + c] = bi;
+            }
+        }
+        __syncthreads();
         for (int c = tid; c < f.rw; c += L0_NT) {
             float best = -INFINITY;
             int bi = -1;
-            for (int r = 0; r < nm; ++r) {
-                const float v = ACT0[r * D + f.zoff + c];
-                if (v > best) {
+#pragma unroll
+            for (int grp = 0; grp < 8; ++grp) {
+                const float v = MV[grp * f.rw + c];
+                const int i = MI_[grp * f.rw + c];
+                if (i >= 0 && v > best) {
                     best = v;
-                    bi = r0 + r;
+                    bi = i;
                 }
             }
             sc_stf(mpb, (unsigned)(c * 8), best);
@@ -817,20 +908,25 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         }
     }
     L0_STAMP(50);
-    if ((G == 2 && K > 0) || f.do_max) ok = l0_barrier<false>(a, b, sflag) && ok;
+    if ((G == 2 && K > 0) || f.do_max) ok = l0_barrier<false>(a, b, sflag, ep) && ok;
     L0_STAMP(51);
     // ------------------------------------------------------------------ combine (block order: deterministic)
     if (G == 2 && K > 0) {
         const int n4 = a.epad / 4;
         const int per = (n4 + a.T - 1) / a.T;
-        const ScBuf xgb = sc_buf(f.xpart + (long)b * a.T * a.epad, (size_t)a.T * a.epad * 4);
+        const float* xg = f.xpart + (long)b * a.T * a.epad;
         for (int i = tid; i < per; i += L0_NT) {
             const int e4 = rb * per + i;
             if (e4 < n4) {
                 f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int t = 0; t < a.T; ++t) {
-                    const f32x4 v = __builtin_bit_cast(f32x4, sc_ld16(xgb, (unsigned)(((long)t * a.epad + e4 * 4) * 4)));
-                    s += v;
+                for (int t0 = 0; t0 < a.T; t0 += 16) {       // sixteen blocks' quads in flight, added in block order
+                    f32x4 v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        v[u] = *reinterpret_cast<const f32x4*>(xg + (long)min(t0 + u, a.T - 1) * a.epad + e4 * 4);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (t0 + u < a.T) s += v[u];
                 }
                 if (!ok) s = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
 #pragma unroll
@@ -843,16 +939,22 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         }
     }
     if (f.do_max && rb == 0) {
-        const ScBuf mgb = sc_buf(f.mpart + (long)b * a.T * f.rw * 2, (size_t)a.T * f.rw * 2 * 4);
+        const float* mg = f.mpart + (long)b * a.T * f.rw * 2;
         for (int c = tid; c < f.rw; c += L0_NT) {
             float best = -INFINITY;
             int bi = -1;
-            for (int t = 0; t < a.T; ++t) {
-                const float v = sc_ldf(mgb, (unsigned)((((long)t * f.rw + c) * 2) * 4));
-                const int i = __float_as_int(sc_ldf(mgb, (unsigned)((((long)t * f.rw + c) * 2 + 1) * 4)));
-                if (i >= 0 && v > best) {            // blocks come in row order: strict > keeps the lowest row on ties
-                    best = v;
-                    bi = i;
+            for (int t0 = 0; t0 < a.T; t0 += 8) {
+                float2 pr[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    pr[u] = *reinterpret_cast<const float2*>(mg + ((long)min(t0 + u, a.T - 1) * f.rw + c) * 2);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = __float_as_int(pr[u].y);
+                    if (t0 + u < a.T && i >= 0 && pr[u].x > best) {   // blocks in row order: strict > keeps the lowest row
+                        best = pr[u].x;
+                        bi = i;
+                    }
                 }
             }
             if (f.mask_readout && nb < N && !(best > 0.f)) {   // a masked (zero) row wins unless a valid row ties it at 0
@@ -925,7 +1027,8 @@ bool l0_geometry(const Level0Fwd& f, L0Geom& g) {
         {
             size_t fl = 0;
             for (int s = 0; s < G; ++s)        // (both stacks' inputs are staged even when they are the same tensor: the
-                fl += (size_t)RB * f.st[s].dims[0] + (size_t)f.st[s].dims[0] * f.st[s].dims[1];   // layout must not depend on pointers)
+                fl += (size_t)RB * f.st[s].dims[0] +                                          // layout must not depend on pointers)
+                      (((size_t)f.st[s].dims[0] * f.st[s].dims[1] + 3) & ~size_t(3));
             int ct = 0;
             for (int s = 0; s < G; ++s) ct += f.st[s].dims[1];
             need(fl + (size_t)RB * ct);
@@ -939,12 +1042,13 @@ bool l0_geometry(const Level0Fwd& f, L0Geom& g) {
                 size_t fl = 0;
                 int ctn = 0;
                 for (int s = 0; s < G; ++s) {
-                    fl += (size_t)f.st[s].dims[l + 1] * f.st[s].dims[l + 2];
+                    fl += ((size_t)f.st[s].dims[l + 1] * f.st[s].dims[l + 2] + 3) & ~size_t(3);
                     ctn += f.st[s].dims[l + 2];
                 }
                 need(slots + fl + (size_t)RB * ctn);                       // ... | next layer's weights | P_{l+1}
             }
         }
+        need((size_t)g.epad + 16 * (size_t)(f.rw > 0 ? f.rw : 0));             // partial products | max-readout merge
         if (K > 0) {
             const int ctpk = ((K + 15) / 16) * 16 + 1;
             need((size_t)4 * RB * ctpk + 2 * (size_t)RB * K);                 // reduce slots | TL | SL
@@ -956,7 +1060,7 @@ bool l0_geometry(const Level0Fwd& f, L0Geom& g) {
         g.lds_act[1] = g.lds_act[0] + ((RB * f.ldz[0] + 3) & ~3);
         g.lds_scr = g.lds_act[1] + (G == 2 ? ((RB * f.ldz[1] + 3) & ~3) : 0);
         g.scr_floats = (int)((scr + 3) & ~size_t(3));
-        g.lds_bytes = ((size_t)g.lds_scr + g.scr_floats + 16) * sizeof(float);
+        g.lds_bytes = ((size_t)g.lds_scr + g.scr_floats + (2 * DP_MAX_LAYERS + 1) * 64 + 16) * sizeof(float);
         if (g.lds_bytes > 159 * 1024) continue;
         g.RB = RB;
         g.T = T;
@@ -977,6 +1081,26 @@ void l0_launch(Seq& q, const L0Args& a, size_t lds_bytes) {
 }  // namespace
 
 size_t level0_bar_ints(int B) { return (size_t)BAR_GRAPH0 + (size_t)BAR_GSTRIDE * B; }
+// write-once exchange regions: one split operand per aggregation pass, one partial block per BatchNorm layer
+static void l0_vs_layout(const Level0Fwd& f, long (&off)[DP_MAX_LAYERS + 1], size_t& total) {
+    const int K8 = ((f.N + 31) / 32) * 4;
+    size_t o = 0;
+    for (int p = 0; p <= f.L; ++p) {
+        int ct = 0;
+        if (p < f.L) for (int s = 0; s < f.G; ++s) ct += f.st[s].dims[p + 1];
+        else ct = f.G == 2 ? f.K : 0;
+        off[p] = (long)o;
+        o += (size_t)f.B * 3 * ((ct + 15) / 16) * K8 * 128;
+    }
+    total = o;
+}
+size_t level0_vs_elems(const Level0Fwd& f) {
+    long off[DP_MAX_LAYERS + 1];
+    size_t total;
+    l0_vs_layout(f, off, total);
+    return total + 64;
+}
+size_t level0_part_floats(const Level0Fwd& f) { return (size_t)(f.L > 1 ? f.L - 1 : 1) * f.B * f.N * f.G * 2 + 4; }
 const int* level0_error_word(const int* bar) { return bar + BAR_ERR; }
 size_t level0_xpart_floats(const Level0Fwd& f) {
     L0Geom g;
@@ -1004,9 +1128,11 @@ bool level0_persistent_ok(const Level0Fwd& f) {
             wfl += (size_t)f.st[s].dims[l] * f.st[s].dims[l + 1];
         }
         if (ct > 96 || wfl > 8192) return false;              // <= 6 column tiles; a layer's weights <= 32 KiB
+        for (int s = 0; s < f.G; ++s)                         // one stack's layer weights: <= 4 quads per thread in flight
+            if ((size_t)f.st[s].dims[l] * f.st[s].dims[l + 1] > 4 * 4 * L0_NT) return false;
     }
     for (int s = 0; s < f.G; ++s)
-        if (f.st[s].dims[0] < 1 || f.st[s].dims[0] > 256 || f.ldz[s] > 160) return false;
+        if (f.st[s].dims[0] < 1 || f.st[s].dims[0] > 256 || f.ldz[s] > 160) return false;      // (x rows: <= 64 x 256 floats)
     if (f.G == 2) {
         if (f.K < 1 || f.K > 16 * L0_NK || (size_t)f.K * f.ldz[1] > 8192) return false;
     }
@@ -1030,6 +1156,10 @@ void level0_forward(Seq& q, const Level0Fwd& f) {
     a.dev_err = device_error_word();
     a.spin_limit = knobs().test_barrier_fail ? 64 : L0_SPIN_LIMIT;
     a.target_bias = knobs().test_barrier_fail ? 1 : 0;
+    {
+        size_t total;
+        l0_vs_layout(f, a.vs_off, total);
+    }
     a.zero_n16 = f.zero_p ? (long)(f.zero_bytes / 16) : 0;
     if (f.zero_p && ((reinterpret_cast<uintptr_t>(f.zero_p) & 15) != 0 || (f.zero_bytes & 15) != 0)) {
         zero_fill(q, f.zero_p, f.zero_bytes);

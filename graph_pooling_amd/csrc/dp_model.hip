@@ -782,7 +782,9 @@ size_t dropout_scratch_floats(const dp_encoder_cfg& c) {
 struct Scratch {
     float* xm[2];
     float *Pj, *Uj, *part, *part_b, *logits, *lvl_part, *part_all;
-    float *xpart, *mpart;    // persistent level-0 kernel: partial pooled products / max-readout partials
+    float *xpart, *mpart;    // persistent level-0 kernel: partial pooled products / max-readout partials,
+    float* l0_part;          // BatchNorm partials per layer,
+    unsigned short* l0_vs;   // split operands per pass (write-once exchange regions, dp_level0.hip)
     unsigned short* vs;      // 3-plane bf16 split of the current V operand (level 0, packed adjacency)
 };
 size_t vs_elems(const dp_encoder_cfg& c) {
@@ -881,6 +883,8 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
         const Level0Fwd f = level0_desc(c);
         s.xpart = q.alloc<float>(level0_xpart_floats(f));
         s.mpart = q.alloc<float>(level0_mpart_floats(f));
+        s.l0_part = q.alloc<float>(level0_part_floats(f));
+        s.l0_vs = q.alloc<unsigned short>(level0_vs_elems(f));
     }
     const size_t dsf = dropout_scratch_floats(c);
     s.xm[0] = dsf ? q.alloc<float>(dsf) : nullptr;
@@ -961,7 +965,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
             f.feat = sv.feat;
             f.argmax = lv.argmax;
             f.pkA = sv.pkA; f.pkAt = sv.pkAt; f.pk_flag = sv.pk_flag;
-            f.vs = sc.vs; f.part = sc.part; f.xpart = sc.xpart; f.mpart = sc.mpart;
+            f.vs = sc.l0_vs; f.part = sc.l0_part; f.xpart = sc.xpart; f.mpart = sc.mpart;
             f.bar = l0_bar;
             f.zero_p = train && !q.dry ? q.ws + bz.begin : nullptr;
             f.zero_bytes = train ? bz.end - bz.begin : 0;
