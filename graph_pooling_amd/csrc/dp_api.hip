@@ -46,6 +46,7 @@ const Knobs& knobs() {
         k.no_row_quads = getenv("DP_NO_ROW_QUADS") != nullptr;
         k.test_barrier_fail = getenv("DP_TEST_BARRIER_FAIL") != nullptr;
         k.no_l0_persist = getenv("DP_NO_L0_PERSIST") != nullptr;
+        k.no_l0_persist_bwd = getenv("DP_NO_L0_PERSIST_BWD") != nullptr;
     });
     return k;
 }

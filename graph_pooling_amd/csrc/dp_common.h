@@ -152,6 +152,7 @@ struct Knobs {
     bool no_rowpart_hook;  // DP_NO_ROWPART_HOOK: BatchNorm-backward partials in a launch of their own
     bool no_widen_fusion;  // DP_NO_WIDEN_FUSION: widening layers' row-local products on the GEMM kernels
     bool no_agg_first;     // DP_NO_AGG_FIRST: every GraphConv as A (x W), also the layers that widen a lot
+    bool no_l0_persist_bwd;  // DP_NO_L0_PERSIST_BWD: only the level-0 BACKWARD as the old launch sequence
     bool no_l0_persist;    // DP_NO_L0_PERSIST: level 0 as the launch sequence of rounds 1-2 instead of the persistent kernel
     bool test_barrier_fail;  // DP_TEST_BARRIER_FAIL: TEST ONLY — grid barriers wait for one arrival too many with a
                              // tiny spin limit, so the give-up path runs (tests/test_gpu_edge_cases.py)
@@ -431,6 +432,44 @@ struct Level0Fwd {
     void* zero_p;                  // side job: clear this region (the backward accumulators), 16-byte aligned
     size_t zero_bytes;
 };
+// ... and its mirror: the whole level-0 backward (pooling products, A V, softmax / assign head backward, every GraphConv
+// layer with BatchNorm backward, A^T dU, weight / bias / input gradients) in ONE persistent launch; the parameter
+// gradients of a graph leave as ONE slab row, combined over the graph's row blocks in block order (deterministic).
+struct Level0Bwd {
+    int B, N, L, G, bn;
+    const float* A;                // fp32 adjacency (only read when it is not bf16-exact)
+    const float* x0[2];
+    const float* params;
+    L0Stack st[2];
+    const float* Y[DP_MAX_LAYERS];
+    const float* invn[DP_MAX_LAYERS];
+    const float* stats[DP_MAX_LAYERS];
+    const float* Z[2];
+    int ldz[2];
+    int coff[2][DP_MAX_LAYERS];
+    int K;
+    long wp_off, bp_off;
+    const float* S;                // [B, N, K]
+    const float* Tt;               // [B, N, K]
+    const float* dXn;              // [B, K, D]   gradient of the pooled features
+    const float* dAn;              // [B, K, K]   gradient of the pooled adjacency
+    const float* d_assign;         // [B, N, K] extra gradient of S (link loss) or null
+    const float* dZe;              // [B, N, D]   gradient of the embedding concat (max-readout scatter)
+    const unsigned short *pkA, *pkAt;
+    int pk_ld;
+    const int* pk_flag;
+    float* slabs;                  // slab row of graph 0 (flat parameter offsets); graphs are slab_gstride floats apart
+    long slab_gstride;
+    unsigned short* vs;            // level0_bwd_vs_elems()
+    float* part;                   // level0_part_floats()-sized
+    float* gpart;                  // level0_bwd_gpart_floats()
+    int* bar;                      // the forward's barrier block (same contract)
+};
+bool level0_bwd_persistent_ok(const Level0Bwd& a);
+size_t level0_bwd_vs_elems(const Level0Bwd& a);
+size_t level0_bwd_part_floats(const Level0Bwd& a);
+size_t level0_bwd_gpart_floats(const Level0Bwd& a);
+void level0_backward(Seq& q, const Level0Bwd& a);
 bool level0_persistent_ok(const Level0Fwd& a);
 size_t level0_bar_ints(int B);
 size_t level0_xpart_floats(const Level0Fwd& a);

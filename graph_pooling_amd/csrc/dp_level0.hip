@@ -160,8 +160,8 @@ __device__ inline void l0_mma(const float* A, int lda, const float* B, int ldb, 
 struct L0Epoch {
     int graph, grid;
 };
-template <bool GRID>
-__device__ inline bool l0_barrier(const L0Args& a, int b, int* sflag /*LDS: [0] ok, [1] failed (sticky)*/, L0Epoch& ep) {
+template <bool GRID, typename Args>
+__device__ inline bool l0_barrier(const Args& a, int b, int* sflag /*LDS: [0] ok, [1] failed (sticky)*/, L0Epoch& ep) {
     ep.graph += 1;
     if (GRID) ep.grid += 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores are acknowledged
@@ -359,8 +359,8 @@ __device__ __forceinline__ void l0_agg_f32(const float* Ag, long rs, long ks, in
 }
 
 // One aggregation pass into the k-quarter slots red[kh][RB][ctp] (the caller sums the four quarters).
-template <int MI, int CTH>
-__device__ __forceinline__ void l0_aggregate_pass(const L0Args& a, const unsigned short* Alds, bool exact, const float* Ag,
+template <int MI, int CTH, typename Args>
+__device__ __forceinline__ void l0_aggregate_pass(const Args& a, const unsigned short* Alds, bool exact, const float* Ag,
                                                   long rs, long ks, int nrows, const unsigned short* vsb, int CTt, float* red,
                                                   int ctp, int rot) {
     constexpr int RB = MI * 16;
@@ -384,13 +384,15 @@ __device__ __forceinline__ void l0_aggregate_pass(const L0Args& a, const unsigne
 #pragma unroll
         for (int cbi = 0; cbi < CTH; ++cbi)
             if (cbi < ncb) {
+                if ((cb0 + cbi) * 16 + l15 < ctp) {       // (a slot row is ctp floats: >= the operand's width, maybe < the tiles')
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    red[(kh * RB + rb * 16 + kq * 4 + r) * ctp + (cb0 + cbi) * 16 + l15] = acc[rb][cbi][r];
+                    for (int r = 0; r < 4; ++r)
+                        red[(kh * RB + rb * 16 + kq * 4 + r) * ctp + (cb0 + cbi) * 16 + l15] = acc[rb][cbi][r];
+                }
             }
 }
-template <int MI>
-__device__ __forceinline__ void l0_aggregate(const L0Args& a, const unsigned short* Alds, bool exact, const float* Ag, long rs,
+template <int MI, typename Args>
+__device__ __forceinline__ void l0_aggregate(const Args& a, const unsigned short* Alds, bool exact, const float* Ag, long rs,
                                              long ks, int nrows, const unsigned short* vsb, int CTt, float* red, int ctp, int rot) {
     const int cth = (CTt + 1) >> 1;
     if (cth <= 1) l0_aggregate_pass<MI, 1>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp, rot);
@@ -991,6 +993,511 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
     }
 }
 
+// =========================================================================================================
+// Level-0 BACKWARD as one persistent launch (the mirror of k_level0_fwd; same decomposition, same barriers).
+//   X' = S^T Z, A' = Tt^T S   ->  dZ += S dX',  dS = Z dX'^T + Tt dA' + A (S dA'^T)      encoders.py:1278-1279
+//   S = softmax(Za Wp^T + bp) * mask  ->  dlogits, dWp, dbp, dZa                          encoders.py:1273-1275
+//   every GraphConv layer, last to first: BatchNorm / ReLU / l2-normalise backward -> dU, bias sums;
+//   G = A^T dU;  dW = x_in^T G;  dx_in += G W^T (+ the BatchNorm-backward partials of the layer below)
+// Parameter gradients: every block stores its partial (compact layout), the graph's blocks sum disjoint slices in block
+// order and write ONE slab row per graph — no float atomics anywhere on this path.
+struct L0BArgs {
+    Level0Bwd f;
+    int T, RB, ldp, K8, steps;
+    long vs_off[DP_MAX_LAYERS + 1];          // pass 0: V = S dA'^T; pass 1 + (L-1-l): dU of layer l
+    int lds_dz[2];                           // float offsets: dZ accumulators [RB][ldz[g]]
+    int lds_scr, slots_floats, scr_floats;   // scratch: [reduce slots | extra]
+    int P0;                                  // compact parameter-gradient floats per block (multiple of 4)
+    int cw[2][DP_MAX_LAYERS], cb[2][DP_MAX_LAYERS], cwp, cbp;   // compact offsets (cb < 0: no bias)
+    int nseg;
+    int seg_c[4 * DP_MAX_LAYERS + 2], seg_len[4 * DP_MAX_LAYERS + 2];
+    long seg_flat[4 * DP_MAX_LAYERS + 2];
+    int* dev_err;
+    int spin_limit, target_bias;
+};
+
+#ifdef DP_STAMP
+__device__ unsigned long long g_l0b_stamps[3][64];
+#define L0B_STAMP(i)                                                                                   \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && (wid == 0 || wid == (int)gridDim.x / 2 || wid == (int)gridDim.x - 1)) \
+            g_l0b_stamps[wid == 0 ? 0 : (wid == (int)gridDim.x - 1 ? 2 : 1)][i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define L0B_STAMP(i) \
+    do {             \
+    } while (0)
+#endif
+
+// Several bulk copies global -> LDS with every load of every region in flight before the first LDS write (regions of
+// up to QN * 4 * 512 floats; larger ones finish in a second round).
+struct L0Copy {
+    float* dst;
+    const float* src;
+    int count, zero_to;
+};
+template <int NJ, int QN>
+__device__ __forceinline__ void l0_copy_many(const L0Copy (&jobs)[NJ]) {
+    f32x4_u q[NJ][QN];
+    float tail[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int nq = jobs[j].count >> 2;
+#pragma unroll
+        for (int u = 0; u < QN; ++u)
+            q[j][u] = *reinterpret_cast<const f32x4_u*>(jobs[j].src + 4 * min(u * L0_NT + (int)threadIdx.x, max(nq - 1, 0)));
+        const int te = (nq << 2) + (int)threadIdx.x;
+        tail[j] = te < jobs[j].count ? jobs[j].src[te] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int nq = jobs[j].count >> 2;
+#pragma unroll
+        for (int u = 0; u < QN; ++u) {
+            const int e4 = u * L0_NT + (int)threadIdx.x;
+            if (e4 < nq) *reinterpret_cast<f32x4*>(jobs[j].dst + 4 * e4) = q[j][u];
+        }
+        const int te = (nq << 2) + (int)threadIdx.x;
+        if (te < jobs[j].count) jobs[j].dst[te] = tail[j];
+        for (int e4 = QN * L0_NT + (int)threadIdx.x; e4 < nq; e4 += L0_NT)          // (regions beyond the batch: rare)
+            *reinterpret_cast<f32x4*>(jobs[j].dst + 4 * e4) = *reinterpret_cast<const f32x4_u*>(jobs[j].src + 4 * e4);
+        for (int e = jobs[j].count + (int)threadIdx.x; e < jobs[j].zero_to; e += L0_NT) jobs[j].dst[e] = 0.f;
+    }
+}
+
+// `len` floats of an LDS staging tile -> this block's compact gradient vector (write-through: the graph's blocks read it)
+__device__ __forceinline__ void l0_put_compact(ScBuf gp, int cstart, const float* stg, int len) {
+    if ((reinterpret_cast<uintptr_t>(stg) & 15) != 0) {        // (a slice of a tile: element by element)
+        for (int e = threadIdx.x; e < len; e += L0_NT) sc_stf(gp, (unsigned)((cstart + e) * 4), stg[e]);
+        return;
+    }
+    const int nq = len >> 2;
+    for (int e4 = threadIdx.x; e4 < nq; e4 += L0_NT)
+        sc_st16(gp, (unsigned)((cstart + e4 * 4) * 4), *reinterpret_cast<const u32x4*>(stg + e4 * 4));
+    const int te = (nq << 2) + (int)threadIdx.x;
+    if (te < len) sc_stf(gp, (unsigned)((cstart + te) * 4), stg[te]);
+}
+
+template <int MI>
+__global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
+    constexpr int RB = MI * 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Level0Bwd& f = a.f;
+    const int tid = threadIdx.x;
+    const int tl = tid & 15, team = tid >> 4;
+    const int N = f.N, G = f.G, L = f.L;
+    int wid;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qd = nwg >> 3, rm = nwg & 7;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int b = wid / a.T, rb = wid - b * a.T;
+    const int r0 = rb * RB;
+    const int nrows = min(RB, N - r0);
+    const int rot = (rb * 4) % a.steps;
+    L0B_STAMP(0);
+
+    unsigned short* Alds = reinterpret_cast<unsigned short*>(lds);
+    float* RA = lds;                                       // the adjacency block's bytes as scratch (before / between passes)
+    float* DZ0 = lds + a.lds_dz[0];                        // [RB][D]   gradient of my rows of Ze (running)
+    float* DZ1 = lds + a.lds_dz[1];                        // [RB][Da]  ... of Za
+    float* SCR = lds + a.lds_scr;                          // [reduce slots | extra]
+    float* EXT = SCR + a.slots_floats;
+    int* sflag = reinterpret_cast<int*>(SCR + a.scr_floats);
+    if (tid < 4) sflag[tid] = 0;
+    L0Epoch ep{0, 0};
+    const bool exact = f.pk_flag[0] == 0;
+    const int D = f.ldz[0], Da = f.ldz[1], K = f.K;
+    const float* Arows = f.A + ((long)b * N + r0) * N;
+    const float* Acols = f.A + (long)b * N * N + r0;
+    const ScBuf gp = sc_buf(f.gpart + ((long)b * a.T + rb) * a.P0, (size_t)a.P0 * 4);
+    const int k8_0 = r0 / 8;
+    const int nk8 = min(rb == a.T - 1 ? a.K8 - k8_0 : RB / 8, a.K8 - k8_0);
+    auto vs_wr = [&](int pass, int CTt) {
+        return sc_buf(f.vs + a.vs_off[pass] + (long)b * 3 * CTt * a.K8 * 128, (size_t)3 * CTt * a.K8 * 128 * 2);
+    };
+    auto vs_rd = [&](int pass, int CTt) { return f.vs + a.vs_off[pass] + (long)b * 3 * CTt * a.K8 * 128; };
+    bool ok = true;
+    __syncthreads();
+
+    // my rows of dZe (the max-readout scatter of the head's backward) start the running gradient
+    if (G == 2 && K > 0) {
+        // ------------------------------------------------------------------ pooling products (row-local)
+        const int CTk = (K + 15) / 16, ctpk = K | 1;
+        float* SL = RA;                                    // [RB][K]
+        float* ZL = SL + RB * K;                           // [RB][D]
+        float* TL = ZL + RB * D;                           // [RB][K]
+        float* DAN = TL + RB * K;                          // [K][K]
+        float* DXN = SCR;                                  // [K][D]     (reduce-slot area: free until the A V pass)
+        float* VL = DXN + ((K * D + 3) & ~3);              // [RB][K]    V = S dA'^T
+        float* DS = EXT;                                   // [RB][K]    Z dX'^T
+        float* DS2 = DS + RB * K;                          // [RB][K]    Tt dA'
+        {
+            const long rowo = (long)b * N + r0;
+            const L0Copy jobs[6] = {{SL, f.S + rowo * K, nrows * K, RB * K},
+                                    {ZL, f.Z[0] + rowo * D, nrows * D, RB * D},
+                                    {TL, f.Tt + rowo * K, nrows * K, RB * K},
+                                    {DAN, f.dAn + (long)b * K * K, K * K, 0},
+                                    {DXN, f.dXn + (long)b * K * D, K * D, 0},
+                                    {DZ0, f.dZe + rowo * D, nrows * D, RB * D}};
+            l0_copy_many<6, 2>(jobs);
+        }
+        __syncthreads();
+        L0B_STAMP(1);
+        l0_mma<false, false>(SL, K, DXN, D, RB, D, K, [&](int r, int j, float v) { DZ0[r * D + j] += v; });
+        l0_mma<false, true>(ZL, D, DXN, D, RB, K, D, [&](int r, int i, float v) { DS[r * K + i] = v; }, 2);
+        l0_mma<false, true>(SL, K, DAN, K, RB, K, K, [&](int r, int i, float v) { VL[r * K + i] = v; }, 4);
+        l0_mma<false, false>(TL, K, DAN, K, RB, K, K, [&](int r, int i, float v) { DS2[r * K + i] = v; }, 6);
+        __syncthreads();
+        L0B_STAMP(2);
+        l0_write_split(vs_wr(0, CTk), VL, K, CTk, a.K8, k8_0, nk8, nrows);
+        {
+            // my rows of the packed A: asked for in front of the barrier, written over the staged rows behind it
+            L0RowStage<MI> q;
+            l0_stage_issue<MI>(q, f.pkA + ((long)b * N + r0) * f.pk_ld, f.pk_ld, nrows, 0);
+            ok = l0_barrier<false>(a, b, sflag, ep) && ok;
+            l0_stage_commit<MI>(q, Alds, a.ldp, f.pk_ld, nrows, 0);
+            const int segs = (a.steps * 32 + 511) / 512;
+            for (int seg = 1; seg < segs; ++seg) {
+                l0_stage_issue<MI>(q, f.pkA + ((long)b * N + r0) * f.pk_ld, f.pk_ld, nrows, seg);
+                l0_stage_commit<MI>(q, Alds, a.ldp, f.pk_ld, nrows, seg);
+            }
+        }
+        __syncthreads();
+        L0B_STAMP(3);
+        // ------------------------------------------------------------------ dS += A V;  softmax backward
+        l0_aggregate<MI>(a, Alds, exact, Arows, N, 1, nrows, vs_rd(0, CTk), CTk, SCR, ctpk, rot);
+        __syncthreads();
+        L0B_STAMP(4);
+        float* DLOG = DS;                                  // in place, row by row
+        for (int r = team; r < RB; r += L0_TEAMS) {
+            const long row = (long)b * N + min(r0 + r, N - 1);
+            float sv[L0_NK], dv[L0_NK];
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                const int c = min(tl + 16 * k, K - 1);
+                sv[k] = f.S[row * K + c];
+                dv[k] = f.d_assign ? f.d_assign[row * K + c] : 0.f;
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                const int c = min(tl + 16 * k, K - 1);
+                const int o = r * ctpk + c;
+                const float agg = (SCR[o] + SCR[RB * ctpk + o]) + (SCR[2 * RB * ctpk + o] + SCR[3 * RB * ctpk + o]);
+                dv[k] += (agg + DS[r * K + c]) + DS2[r * K + c];
+                dot += (tl + 16 * k < K) ? sv[k] * dv[k] : 0.f;
+            }
+            dot = row16_sum(dot);
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                const int c = tl + 16 * k;
+                if (c < K) DLOG[r * K + c] = r < nrows ? sv[k] * (dv[k] - dot) : 0.f;
+            }
+        }
+        __syncthreads();
+        L0B_STAMP(5);
+        // assign_pred: dWp = dlog^T Za, dbp = column sums, dZa = dlog Wp
+        {
+            float* ZAL = SCR;                              // [RB][Da]  (the reduce slots are free again)
+            float* WP = ZAL + ((RB * Da + 3) & ~3);        // [K][Da]
+            float* STG = RA;                               // staging of the parameter gradients (the A block is done with)
+            const L0Copy jobs[2] = {{ZAL, f.Z[1] + ((long)b * N + r0) * Da, nrows * Da, RB * Da},
+                                    {WP, f.params + f.wp_off, K * Da, 0}};
+            l0_copy_many<2, 3>(jobs);
+            __syncthreads();
+            l0_mma<true, false>(DLOG, K, ZAL, Da, K, Da, RB, [&](int i, int j, float v) { STG[i * Da + j] = v; });
+            l0_mma<false, false>(DLOG, K, WP, Da, RB, Da, K, [&](int r, int j, float v) { DZ1[r * Da + j] = v; }, 4);
+            float* SB = STG + ((K * Da + 3) & ~3);
+            for (int c = tid; c < K; c += L0_NT) {
+                float t = 0.f;
+                for (int r = 0; r < RB; ++r) t += DLOG[r * K + c];
+                SB[c] = t;
+            }
+            __syncthreads();
+            l0_put_compact(gp, a.cwp, STG, K * Da);
+            if (a.cbp >= 0) l0_put_compact(gp, a.cbp, SB, K);
+        }
+        L0B_STAMP(6);
+    } else {
+        const L0Copy jobs[1] = {{DZ0, f.dZe + ((long)b * N + r0) * D, nrows * D, RB * D}};
+        l0_copy_many<1, 4>(jobs);
+        if (G == 2)
+            for (int e = tid; e < RB * Da; e += L0_NT) DZ1[e] = 0.f;
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ the GraphConv layers, last to first
+    constexpr int ITEMS = (RB * 2 + L0_TEAMS - 1) / L0_TEAMS;
+    bool have_at = false;
+    for (int l = L - 1; l >= 0; --l) {
+        const bool last = l == L - 1;
+        const bool has_bn = !last && f.bn;
+        const int w0 = f.st[0].dims[l + 1], w1 = G == 2 ? f.st[1].dims[l + 1] : 0;
+        const int d0 = f.st[0].dims[l], d1 = G == 2 ? f.st[1].dims[l] : 0;
+        const int ct = w0 + w1, wmax = max(w0, w1);
+        const int CTt = (ct + 15) / 16, ctp = ct | 1;
+        const int pass = 1 + (L - 1 - l);
+        float* DU = SCR;                                   // [RB][ct]  (reduce-slot area: free until the pass)
+        // ---- BatchNorm / ReLU / l2-normalise backward of my rows -> dU
+        {
+            const float* partr = f.part + (long)l * f.B * N * G * 2;
+            float p0[ITEMS][L0_BPAIRS], p1[ITEMS][L0_BPAIRS];
+            float yv[ITEMS][L0_NK], xh[ITEMS][L0_NK];
+            float rstd_[ITEMS], inv_[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int it = team + j * L0_TEAMS;
+                const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+                const int node = min(r0 + r, N - 1);
+                const long row = (long)b * N + node;
+                const int wg = g ? w1 : w0, c0gg = g ? w0 : 0;
+                const float* yp = last ? f.Z[g] + row * f.ldz[g] + f.coff[g][l] : f.Y[l] + row * ct + c0gg;
+                const float* xp = f.Z[g] + row * f.ldz[g] + f.coff[g][l];
+#pragma unroll
+                for (int k = 0; k < L0_NK; ++k) {
+                    const int c = min(tl + 16 * k, wg - 1);
+                    yv[j][k] = yp[c];
+                    xh[j][k] = xp[c];
+                }
+                inv_[j] = f.invn[l][row * G + g];
+                rstd_[j] = has_bn ? f.stats[l][((long)node * G + g) * 2 + 1] : 1.f;
+                if (has_bn) {
+#pragma unroll
+                    for (int u = 0; u < L0_BPAIRS; ++u) {
+                        const float2 pr = *reinterpret_cast<const float2*>(
+                            partr + ((((long)node * G + g) * f.B) + min(tl + 16 * u, f.B - 1)) * 2);
+                        p0[j][u] = pr.x;
+                        p1[j][u] = pr.y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int it = team + j * L0_TEAMS;
+                const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+                const int wg = g ? w1 : w0, c0gg = g ? w0 : 0;
+                float m0 = 0.f, m1 = 0.f;
+                if (has_bn) {
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int u = 0; u < L0_BPAIRS; ++u) {
+                        s0 += (tl + 16 * u < f.B) ? p0[j][u] : 0.f;
+                        s1 += (tl + 16 * u < f.B) ? p1[j][u] : 0.f;
+                    }
+                    const float cnt = (float)f.B * (float)wg;
+                    m0 = row16_sum(s0) / cnt;
+                    m1 = row16_sum(s1) / cnt;
+                    if (!ok) m0 = __builtin_nanf("");
+                }
+                const float* dzr = (g ? DZ1 : DZ0) + r * f.ldz[g] + f.coff[g][l];
+                const float inv = inv_[j];
+                const bool project = inv < 1.0f / L0_L2_EPS;
+                float dv[L0_NK];
+                float dot = 0.f;
+#pragma unroll
+                for (int k = 0; k < L0_NK; ++k) {
+                    dv[k] = 0.f;
+                    if (16 * k < wmax) {
+                        float d = dzr[min(tl + 16 * k, wg - 1)];
+                        if (has_bn) d = rstd_[j] * (d - m0 - xh[j][k] * m1);
+                        if (!last) d = yv[j][k] > 0.f ? d : 0.f;
+                        if (tl + 16 * k >= wg) d = 0.f;
+                        dv[k] = d;
+                        dot += d * yv[j][k];
+                    }
+                }
+                dot = row16_sum(dot);
+#pragma unroll
+                for (int k = 0; k < L0_NK; ++k) {
+                    const int c = tl + 16 * k;
+                    if (16 * k < wmax && c < wg && it < RB * G) {
+                        const float v = project ? inv * (dv[k] - yv[j][k] * dot) : inv * dv[k];
+                        DU[r * ct + c0gg + c] = r < nrows ? v : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        L0B_STAMP(8 + 8 * (L - 1 - l));
+        // bias gradients: column sums of dU over my rows
+        {
+            float* SB = EXT;
+            for (int c = tid; c < ct; c += L0_NT) {
+                float t = 0.f;
+                for (int r = 0; r < RB; ++r) t += DU[r * ct + c];
+                SB[c] = t;
+            }
+        }
+        l0_write_split(vs_wr(pass, CTt), DU, ct, CTt, a.K8, k8_0, nk8, nrows);
+        __syncthreads();
+        if (a.cb[0][l] >= 0) l0_put_compact(gp, a.cb[0][l], EXT, w0);
+        if (G == 2 && a.cb[1][l] >= 0) l0_put_compact(gp, a.cb[1][l], EXT + w0, w1);
+        // layer input rows (the left operand of dW, and xhat of the layer below) + this layer's weights: asked for now,
+        // they land under the barrier
+        // (layer 0: the second stack's input rows do not fit beside the first's — they go to the adjacency block's bytes
+        // once the last pass is over)
+        float* XIN0 = EXT + ((ct + 3) & ~3);
+        float* XIN1 = l > 0 ? XIN0 + RB * d0 : RA;
+        float* W0 = XIN1 + RB * d1;                        // (l > 0 only)
+        float* W1 = W0 + ((d0 * w0 + 3) & ~3);
+        {
+            const long rowo = (long)b * N + r0;
+            if (l > 0) {
+                // the previous layer's slices of the concat buffers are column slices: row by row
+                for (int e = tid; e < RB * d0; e += L0_NT) {
+                    const int r = e / d0, k = e - r * d0;
+                    XIN0[e] = r < nrows ? f.Z[0][(rowo + r) * f.ldz[0] + f.coff[0][l - 1] + k] : 0.f;
+                }
+                if (G == 2)
+                    for (int e = tid; e < RB * d1; e += L0_NT) {
+                        const int r = e / d1, k = e - r * d1;
+                        XIN1[e] = r < nrows ? f.Z[1][(rowo + r) * f.ldz[1] + f.coff[1][l - 1] + k] : 0.f;
+                    }
+                const L0Copy jw[2] = {{W0, f.params + f.st[0].w_off[l], d0 * w0, 0},
+                                      {W1, G == 2 ? f.params + f.st[1].w_off[l] : f.params, G == 2 ? d1 * w1 : 0, 0}};
+                l0_copy_many<2, 2>(jw);
+            } else {
+                const L0Copy jx[1] = {{XIN0, f.x0[0] + rowo * d0, nrows * d0, RB * d0}};
+                l0_copy_many<1, 4>(jx);
+            }
+        }
+        L0B_STAMP(9 + 8 * (L - 1 - l));
+        if (!have_at) {
+            L0RowStage<MI> q;
+            l0_stage_issue<MI>(q, f.pkAt + ((long)b * N + r0) * f.pk_ld, f.pk_ld, nrows, 0);
+            ok = l0_barrier<false>(a, b, sflag, ep) && ok;
+            l0_stage_commit<MI>(q, Alds, a.ldp, f.pk_ld, nrows, 0);
+            const int segs = (a.steps * 32 + 511) / 512;
+            for (int seg = 1; seg < segs; ++seg) {
+                l0_stage_issue<MI>(q, f.pkAt + ((long)b * N + r0) * f.pk_ld, f.pk_ld, nrows, seg);
+                l0_stage_commit<MI>(q, Alds, a.ldp, f.pk_ld, nrows, seg);
+            }
+            have_at = true;
+            __syncthreads();
+        } else {
+            ok = l0_barrier<false>(a, b, sflag, ep) && ok;
+        }
+        L0B_STAMP(10 + 8 * (L - 1 - l));
+        // ---- G = A^T dU (my rows), summed in place into the first reduce slot
+        l0_aggregate<MI>(a, Alds, exact, Acols, 1, N, nrows, vs_rd(pass, CTt), CTt, SCR, ctp, rot);
+        __syncthreads();
+        L0B_STAMP(11 + 8 * (L - 1 - l));
+        float* Gt = SCR;                                   // [RB][ctp]
+        for (int e = tid; e < RB * ct; e += L0_NT) {
+            const int r = e / ct, c = e - r * ct;
+            const int o = r * ctp + c;
+            const float v = (SCR[o] + SCR[RB * ctp + o]) + (SCR[2 * RB * ctp + o] + SCR[3 * RB * ctp + o]);
+            Gt[o] = r < nrows ? v : 0.f;
+        }
+        __syncthreads();
+        L0B_STAMP(12 + 8 * (L - 1 - l));
+        if (l == 0 && G == 2) {
+            const L0Copy jx[1] = {{XIN1, f.x0[1] + ((long)b * N + r0) * d1, nrows * d1, RB * d1}};
+            l0_copy_many<1, 4>(jx);
+            __syncthreads();
+        }
+        // ---- dW = x_in^T G  (staged behind the first slot);  dx_in += G W^T
+        float* STG0 = SCR + RB * ctp;
+        float* STG1 = STG0 + ((d0 * w0 + 3) & ~3);
+        l0_mma<true, false>(XIN0, d0, Gt, ctp, d0, w0, RB, [&](int i, int j, float v) { STG0[i * w0 + j] = v; });
+        if (G == 2)
+            l0_mma<true, false>(XIN1, d1, Gt + w0, ctp, d1, w1, RB, [&](int i, int j, float v) { STG1[i * w1 + j] = v; }, 3);
+        if (l > 0) {
+            float* dz0 = DZ0 + f.coff[0][l - 1];
+            l0_mma<false, true>(Gt, ctp, W0, w0, RB, d0, w0, [&](int r, int k, float v) { dz0[r * D + k] += v; }, 5);
+            if (G == 2) {
+                float* dz1 = DZ1 + f.coff[1][l - 1];
+                l0_mma<false, true>(Gt + w0, ctp, W1, w1, RB, d1, w1, [&](int r, int k, float v) { dz1[r * Da + k] += v; }, 7);
+            }
+        }
+        __syncthreads();
+        L0B_STAMP(13 + 8 * (L - 1 - l));
+        l0_put_compact(gp, a.cw[0][l], STG0, d0 * w0);
+        if (G == 2) l0_put_compact(gp, a.cw[1][l], STG1, d1 * w1);
+        if (l > 0 && f.bn) {
+            // BatchNorm-backward partials of layer l - 1: (sum dx, sum dx * xhat) per (row, group); xhat = the layer input
+            const ScBuf partw = sc_buf(f.part + (long)(l - 1) * f.B * N * G * 2, (size_t)f.B * N * G * 2 * sizeof(float));
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int it = team + j * L0_TEAMS;
+                const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+                const bool on = it < RB * G && r < nrows;
+                const int dg = g ? d1 : d0;
+                const float* dzr = (g ? DZ1 : DZ0) + r * f.ldz[g] + f.coff[g][l - 1];
+                const float* xr = (g ? XIN1 : XIN0) + r * dg;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < L0_NK; ++k) {
+                    const int c = min(tl + 16 * k, dg - 1);
+                    const float d = (tl + 16 * k < dg) ? dzr[c] : 0.f;
+                    s0 += d;
+                    s1 += d * xr[c];
+                }
+                s0 = row16_sum(s0);
+                s1 = row16_sum(s1);
+                if (on && tl == 0) {
+                    const long po = ((((long)min(r0 + r, N - 1) * G + g) * f.B + b) * 2) * 4;
+                    sc_stf(partw, (unsigned)po, s0);
+                    sc_stf(partw, (unsigned)(po + 4), s1);
+                }
+            }
+            L0B_STAMP(14 + 8 * (L - 1 - l));
+            ok = l0_barrier<true>(a, b, sflag, ep) && ok;
+        } else {
+            __syncthreads();
+        }
+        L0B_STAMP(15 + 8 * (L - 1 - l));
+    }
+    // ------------------------------------------------------------------ the graph's parameter gradients: one slab row
+    ok = l0_barrier<false>(a, b, sflag, ep) && ok;
+    L0B_STAMP(40);
+    {
+        const int n4 = a.P0 / 4;
+        const int per = (n4 + a.T - 1) / a.T;
+        const float* gg = f.gpart + (long)b * a.T * a.P0;
+        float* slab = f.slabs + (long)b * f.slab_gstride;
+        for (int i = tid; i < per; i += L0_NT) {
+            const int e4 = rb * per + i;
+            if (e4 < n4) {
+                f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int t0 = 0; t0 < a.T; t0 += 16) {
+                    f32x4 v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        v[u] = *reinterpret_cast<const f32x4*>(gg + (long)min(t0 + u, a.T - 1) * a.P0 + e4 * 4);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (t0 + u < a.T) s += v[u];
+                }
+                if (!ok) s = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                int sg = 0;
+                while (sg + 1 < a.nseg && a.seg_c[sg + 1] <= e4 * 4) ++sg;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e4 * 4 + j - a.seg_c[sg];        // (segments start on quads: a quad never straddles two)
+                    if (e < a.seg_len[sg]) slab[a.seg_flat[sg] + e] = s[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    L0B_STAMP(41);
+    if (tid == 0) {
+        const int old = ag_add(f.bar + BAR_DONE, 1);
+        sflag[3] = old == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (sflag[3]) {
+        for (int g = tid; g < f.B; g += L0_NT) ag_st(f.bar + BAR_GRAPH0 + g * BAR_GSTRIDE, 0);
+        if (tid == 0) {
+            ag_st(f.bar + BAR_GCOUNT, 0);
+            ag_st(f.bar + BAR_DONE, 0);
+        }
+    }
+}
+
 struct L0Geom {
     int RB, T, ldp, K8, steps, epad;
     int lds_act[2], lds_scr, scr_floats;
@@ -1173,6 +1680,171 @@ void level0_forward(Seq& q, const Level0Fwd& f) {
         default: l0_launch<4>(q, a, g.lds_bytes); break;
     }
 }
+
+// ------------------------------------------------------------------ backward: geometry, compact layout, launch
+namespace {
+struct L0BGeom {
+    int RB, T, ldp, K8, steps;
+    int lds_dz[2], lds_scr, slots_floats, scr_floats;
+    size_t lds_bytes;
+};
+Level0Fwd l0_as_fwd(const Level0Bwd& f) {          // the fields the shared geometry / envelope helpers read
+    Level0Fwd w{};
+    w.B = f.B; w.N = f.N; w.L = f.L; w.G = f.G; w.bn = f.bn;
+    w.st[0] = f.st[0]; w.st[1] = f.st[1];
+    w.ldz[0] = f.ldz[0]; w.ldz[1] = f.ldz[1];
+    w.K = f.K;
+    return w;
+}
+bool l0b_geometry(const Level0Bwd& f, L0BGeom& g) {
+    // the SAME block size as the forward pass (the two launches share nothing but the barrier block, but one
+    // decomposition keeps the workspace sizing in one place)
+    L0Geom fg;
+    Level0Fwd w = l0_as_fwd(f);
+    w.do_max = 0;
+    if (!l0_geometry(w, fg)) return false;
+    const int RB = fg.RB, N = f.N, G = f.G, L = f.L;
+    const int K = G == 2 ? f.K : 0, D = f.ldz[0], Da = G == 2 ? f.ldz[1] : 0;
+    g.RB = RB; g.T = fg.T; g.ldp = fg.ldp; g.K8 = fg.K8; g.steps = fg.steps;
+    const size_t ra = ((size_t)RB * g.ldp * 2 + 15) / 16 * 4;               // floats
+    size_t slots = 0, ext = 0;
+    auto S_ = [&](size_t v) { slots = v > slots ? v : slots; };
+    auto E_ = [&](size_t v) { ext = v > ext ? v : ext; };
+    if (K > 0) {
+        if ((size_t)2 * RB * K + (size_t)RB * D + (size_t)K * K > ra) return false;          // staged rows in the block's bytes
+        if ((size_t)K * Da + K + 8 > ra) return false;                                        // dWp | dbp staging
+        S_((size_t)4 * RB * (K | 1));
+        S_((((size_t)K * D + 3) & ~size_t(3)) + (size_t)RB * K);                               // dX' | V
+        S_((((size_t)RB * Da + 3) & ~size_t(3)) + (size_t)K * Da);                             // Za rows | Wp
+        E_((size_t)2 * RB * K);
+    }
+    for (int l = 0; l < L; ++l) {
+        int ct = 0, din = 0;
+        size_t wfl = 0;
+        for (int s2 = 0; s2 < G; ++s2) {
+            ct += f.st[s2].dims[l + 1];
+            din += f.st[s2].dims[l];
+            wfl += ((size_t)f.st[s2].dims[l] * f.st[s2].dims[l + 1] + 3) & ~size_t(3);
+        }
+        const size_t ctp = (size_t)(ct | 1);
+        S_((size_t)4 * RB * ctp);
+        S_((size_t)RB * ctp + wfl);                                                            // G | staged dW
+        if (l > 0) E_((((size_t)ct + 3) & ~size_t(3)) + (size_t)RB * din + wfl);
+        else {
+            E_((((size_t)ct + 3) & ~size_t(3)) + (size_t)RB * f.st[0].dims[0]);
+            if (G == 2 && (size_t)RB * f.st[1].dims[0] > ra) return false;
+        }
+    }
+    g.lds_dz[0] = (int)ra;
+    g.lds_dz[1] = g.lds_dz[0] + ((RB * D + 3) & ~3);
+    g.lds_scr = g.lds_dz[1] + (G == 2 ? ((RB * Da + 3) & ~3) : 0);
+    g.slots_floats = (int)((slots + 3) & ~size_t(3));
+    g.scr_floats = g.slots_floats + (int)((ext + 3) & ~size_t(3));
+    g.lds_bytes = ((size_t)g.lds_scr + g.scr_floats + 16) * sizeof(float);
+    return g.lds_bytes <= 160 * 1024;
+}
+// compact parameter-gradient layout of one block: every tensor starts on a quad
+void l0b_compact(const Level0Bwd& f, L0BArgs& a) {
+    int o = 0, ns = 0;
+    auto seg = [&](int& dst, long flat, int len) {
+        dst = o;
+        a.seg_c[ns] = o;
+        a.seg_flat[ns] = flat;
+        a.seg_len[ns] = len;
+        ++ns;
+        o += (len + 3) & ~3;
+    };
+    for (int l = 0; l < f.L; ++l)
+        for (int g = 0; g < f.G; ++g) {
+            seg(a.cw[g][l], f.st[g].w_off[l], f.st[g].dims[l] * f.st[g].dims[l + 1]);
+            if (f.st[g].b_off[l] >= 0) seg(a.cb[g][l], f.st[g].b_off[l], f.st[g].dims[l + 1]);
+            else a.cb[g][l] = -1;
+        }
+    a.cwp = a.cbp = -1;
+    if (f.G == 2 && f.K > 0) {
+        seg(a.cwp, f.wp_off, f.K * f.ldz[1]);
+        if (f.bp_off >= 0) seg(a.cbp, f.bp_off, f.K);
+    }
+    a.nseg = ns;
+    a.P0 = o;
+}
+void l0b_vs_layout(const Level0Bwd& f, long (&off)[DP_MAX_LAYERS + 1], size_t& total) {
+    const int K8 = ((f.N + 31) / 32) * 4;
+    size_t o = 0;
+    for (int p = 0; p <= f.L; ++p) {
+        int ct = 0;
+        if (p == 0) ct = f.G == 2 ? f.K : 0;
+        else for (int s2 = 0; s2 < f.G; ++s2) ct += f.st[s2].dims[f.L - p + 1];          // pass 1 + (L-1-l): layer l = L - p
+        off[p] = (long)o;
+        o += (size_t)f.B * 3 * ((ct + 15) / 16) * K8 * 128;
+    }
+    total = o;
+}
+template <int MI>
+void l0b_launch(Seq& q, const L0BArgs& a, size_t lds_bytes) {
+    static DynLdsOnce attr;
+    ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_level0_bwd<MI>), 160 * 1024, "k_level0_bwd");
+    if (!q.ok()) return;
+    hipLaunchKernelGGL(k_level0_bwd<MI>, dim3(a.f.B * a.T), dim3(L0_NT), lds_bytes, q.stream, a);
+    q.check_launch("level0_backward");
+}
+}  // namespace
+
+bool level0_bwd_persistent_ok(const Level0Bwd& f) {
+    Level0Fwd w = l0_as_fwd(f);
+    w.do_max = 0;
+    if (!level0_persistent_ok(w)) return false;
+    L0BGeom g;
+    return l0b_geometry(f, g);
+}
+size_t level0_bwd_vs_elems(const Level0Bwd& f) {
+    long off[DP_MAX_LAYERS + 1];
+    size_t total;
+    l0b_vs_layout(f, off, total);
+    return total + 64;
+}
+size_t level0_bwd_part_floats(const Level0Bwd& f) { return (size_t)(f.L > 1 ? f.L - 1 : 1) * f.B * f.N * f.G * 2 + 4; }
+size_t level0_bwd_gpart_floats(const Level0Bwd& f) {
+    L0BGeom g;
+    if (!l0b_geometry(f, g)) return 4;
+    L0BArgs a{};
+    l0b_compact(f, a);
+    return (size_t)f.B * g.T * a.P0 + 4;
+}
+void level0_backward(Seq& q, const Level0Bwd& f) {
+    if (!q.ok()) return;
+    L0BGeom g;
+    if (!l0b_geometry(f, g)) {
+        set_error("level0_backward: shape outside the persistent kernel's envelope");
+        q.err = DP_ERR_UNSUPPORTED;
+        return;
+    }
+    L0BArgs a{};
+    a.f = f;
+    a.T = g.T; a.RB = g.RB; a.ldp = g.ldp; a.K8 = g.K8; a.steps = g.steps;
+    a.lds_dz[0] = g.lds_dz[0]; a.lds_dz[1] = g.lds_dz[1];
+    a.lds_scr = g.lds_scr; a.slots_floats = g.slots_floats; a.scr_floats = g.scr_floats;
+    l0b_compact(f, a);
+    {
+        size_t total;
+        l0b_vs_layout(f, a.vs_off, total);
+    }
+    a.dev_err = device_error_word();
+    a.spin_limit = knobs().test_barrier_fail ? 64 : L0_SPIN_LIMIT;
+    a.target_bias = knobs().test_barrier_fail ? 1 : 0;
+    switch (g.RB / 16) {
+        case 1: l0b_launch<1>(q, a, g.lds_bytes); break;
+        case 2: l0b_launch<2>(q, a, g.lds_bytes); break;
+        case 3: l0b_launch<3>(q, a, g.lds_bytes); break;
+        default: l0b_launch<4>(q, a, g.lds_bytes); break;
+    }
+}
+
+#ifdef DP_STAMP
+extern "C" __attribute__((visibility("default"))) int dp_debug_l0b_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_l0b_stamps), sizeof(unsigned long long) * 3 * 64);
+}
+#endif
 
 #ifdef DP_STAMP
 extern "C" __attribute__((visibility("default"))) int dp_debug_l0_stamps(unsigned long long* out) {

@@ -852,6 +852,22 @@ Level0Fwd level0_desc(const dp_encoder_cfg& c) {
     f.pk_ld = adj_pack_ld(c.N);
     return f;
 }
+Level0Bwd level0_bwd_desc(const dp_encoder_cfg& c) {
+    const Level0Fwd w = level0_desc(c);
+    Level0Bwd f{};
+    f.B = w.B; f.N = w.N; f.L = w.L; f.G = w.G; f.bn = w.bn;
+    f.st[0] = w.st[0]; f.st[1] = w.st[1];
+    f.ldz[0] = w.ldz[0]; f.ldz[1] = w.ldz[1];
+    for (int g = 0; g < 2; ++g)
+        for (int l = 0; l < DP_MAX_LAYERS; ++l) f.coff[g][l] = w.coff[g][l];
+    f.K = w.K; f.wp_off = w.wp_off; f.bp_off = w.bp_off;
+    f.pk_ld = w.pk_ld;
+    return f;
+}
+bool level0_persistent(const dp_encoder_cfg& c);
+bool level0_bwd_persistent(const dp_encoder_cfg& c) {
+    return level0_persistent(c) && !knobs().no_l0_persist_bwd && level0_bwd_persistent_ok(level0_bwd_desc(c));
+}
 bool level0_persistent(const dp_encoder_cfg& c) {
     if (bn_sync(c) || (c.flags & DP_F_ADD_SELF)) return false;
     const LevelInfo li = level_info(c, 0);
@@ -1072,8 +1088,17 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     // ---- workspace walk
     size_t maxPU = 0, maxPart = 0, maxSK = 0, maxMeans = 0;
     // (the forward's barrier block, then) zero-initialised gradient accumulators + slabs: ONE block (alloc_bwd_zero)
-    (void)q.alloc<int>(level0_bar_ints(c.B));
+    int* l0_bar = q.alloc<int>(level0_bar_ints(c.B));
     const BwdZero bz = alloc_bwd_zero(q, c);
+    const bool l0_persist = level0_bwd_persistent(c);
+    unsigned short* l0_vs = nullptr;
+    float *l0_part = nullptr, *l0_gpart = nullptr;
+    if (l0_persist) {
+        const Level0Bwd f0 = level0_bwd_desc(c);
+        l0_vs = q.alloc<unsigned short>(level0_bwd_vs_elems(f0));
+        l0_part = q.alloc<float>(level0_bwd_part_floats(f0));
+        l0_gpart = q.alloc<float>(level0_bwd_gpart_floats(f0));
+    }
     LevelGrad gr[DP_MAX_LEVELS + 1]{};
     for (int j = 0; j <= P; ++j) gr[j] = bz.gr[j];
     const int KS = node_ksplit(c);
@@ -1186,6 +1211,34 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
         io.xm[0] = xm[0];
         io.xm[1] = xm[1];
         const int n = li.n;
+        if (j == 0 && l0_persist) {
+            // the whole level in ONE persistent launch (dp_level0.hip): pooling products, A V, softmax / assign head
+            // backward, every GraphConv layer; each graph's parameter gradients arrive as its first slab row
+            Level0Bwd f = level0_bwd_desc(c);
+            f.A = adj;
+            f.x0[0] = x;
+            f.x0[1] = assign_x;
+            f.params = params;
+            for (int l = 0; l < li.L; ++l) {
+                f.Y[l] = lv.layer[l].Y;
+                f.invn[l] = lv.layer[l].invn;
+                f.stats[l] = lv.layer[l].stats;
+            }
+            f.Z[0] = lv.Ze;
+            f.Z[1] = lv.Za;
+            f.S = lv.S; f.Tt = lv.T;
+            f.dXn = P >= 1 ? gr[1].dX0 : nullptr;
+            f.dAn = P >= 1 ? gr[1].dAdj : nullptr;
+            f.d_assign = d_assign;
+            f.dZe = gr[0].dZe;
+            f.pkA = sv.pkA; f.pkAt = sv.pkAt; f.pk_flag = sv.pk_flag;
+            f.slabs = slabs;
+            f.slab_gstride = slab_stride * KS;
+            f.vs = l0_vs; f.part = l0_part; f.gpart = l0_gpart;
+            f.bar = l0_bar;
+            level0_backward(q, f);
+            continue;
+        }
         if (j < P) {
             const int K = li.K, D = li.D;
             bool vsplit_used = false;
