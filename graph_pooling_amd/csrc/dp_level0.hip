@@ -124,15 +124,34 @@ __device__ inline void l0_mma(const float* A, int lda, const float* B, int ldb, 
         const float* bp = (TB ? B + min(j, N - 1) * ldb : B + min(j, N - 1)) + kq * (sb4 >> 2);
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
         int k = 0;
-        for (; k + 16 <= K; k += 16) {
-            const float a0 = ap[0], a1 = ap[sa4], a2 = ap[2 * sa4], a3 = ap[3 * sa4];
-            const float b0 = bp[0], b1 = bp[sb4], b2 = bp[2 * sb4], b3 = bp[3 * sb4];
+        // 16-deep batches, software-pipelined over two register sets: the eight LDS reads of the next batch are in
+        // flight under the four MFMAs of this one (with one set the loop was LDS-latency-bound: ~250 cycles per batch
+        // against 128 of MFMA issue)
+        float pa[4], pb[4], qa[4], qb[4];
+        auto ld = [&](float (&xa)[4], float (&xb)[4]) {
+            xa[0] = ap[0]; xa[1] = ap[sa4]; xa[2] = ap[2 * sa4]; xa[3] = ap[3 * sa4];
+            xb[0] = bp[0]; xb[1] = bp[sb4]; xb[2] = bp[2 * sb4]; xb[3] = bp[3 * sb4];
             ap += 4 * sa4;
             bp += 4 * sb4;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc1, 0, 0, 0);
+        };
+        auto mm = [&](const float (&xa)[4], const float (&xb)[4]) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0], xb[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1], xb[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[2], xb[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[3], xb[3], acc1, 0, 0, 0);
+        };
+        if (k + 16 <= K) ld(pa, pb);
+        while (k + 16 <= K) {
+            const bool more = k + 32 <= K;
+            if (more) ld(qa, qb);
+            mm(pa, pb);
+            k += 16;
+            if (!more) break;
+            const bool more2 = k + 32 <= K;
+            if (more2) ld(pa, pb);
+            mm(qa, qb);
+            k += 16;
+            if (!more2) break;
         }
         for (; k + 4 <= K; k += 4) {
             const float a0 = ap[0], b0 = bp[0];
@@ -1240,82 +1259,88 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
         const int CTt = (ct + 15) / 16, ctp = ct | 1;
         const int pass = 1 + (L - 1 - l);
         float* DU = SCR;                                   // [RB][ct]  (reduce-slot area: free until the pass)
-        // ---- BatchNorm / ReLU / l2-normalise backward of my rows -> dU
-        {
+        // ---- BatchNorm-backward means of my node indices: every graph's (sum dx, sum dx xhat) partials -> (m0, m1) in LDS
+        float* M01 = EXT;                                  // [RB * G][2]
+        if (has_bn) {
             const float* partr = f.part + (long)l * f.B * N * G * 2;
             float p0[ITEMS][L0_BPAIRS], p1[ITEMS][L0_BPAIRS];
-            float yv[ITEMS][L0_NK], xh[ITEMS][L0_NK];
-            float rstd_[ITEMS], inv_[ITEMS];
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 const int it = team + j * L0_TEAMS;
                 const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
                 const int node = min(r0 + r, N - 1);
-                const long row = (long)b * N + node;
-                const int wg = g ? w1 : w0, c0gg = g ? w0 : 0;
-                const float* yp = last ? f.Z[g] + row * f.ldz[g] + f.coff[g][l] : f.Y[l] + row * ct + c0gg;
-                const float* xp = f.Z[g] + row * f.ldz[g] + f.coff[g][l];
 #pragma unroll
-                for (int k = 0; k < L0_NK; ++k) {
-                    const int c = min(tl + 16 * k, wg - 1);
-                    yv[j][k] = yp[c];
-                    xh[j][k] = xp[c];
-                }
-                inv_[j] = f.invn[l][row * G + g];
-                rstd_[j] = has_bn ? f.stats[l][((long)node * G + g) * 2 + 1] : 1.f;
-                if (has_bn) {
-#pragma unroll
-                    for (int u = 0; u < L0_BPAIRS; ++u) {
-                        const float2 pr = *reinterpret_cast<const float2*>(
-                            partr + ((((long)node * G + g) * f.B) + min(tl + 16 * u, f.B - 1)) * 2);
-                        p0[j][u] = pr.x;
-                        p1[j][u] = pr.y;
-                    }
+                for (int u = 0; u < L0_BPAIRS; ++u) {
+                    const float2 pr = *reinterpret_cast<const float2*>(
+                        partr + ((((long)node * G + g) * f.B) + min(tl + 16 * u, f.B - 1)) * 2);
+                    p0[j][u] = pr.x;
+                    p1[j][u] = pr.y;
                 }
             }
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 const int it = team + j * L0_TEAMS;
-                const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
-                const int wg = g ? w1 : w0, c0gg = g ? w0 : 0;
-                float m0 = 0.f, m1 = 0.f;
-                if (has_bn) {
-                    float s0 = 0.f, s1 = 0.f;
+                const int g = G == 2 ? (it & 1) : 0;
+                float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-                    for (int u = 0; u < L0_BPAIRS; ++u) {
-                        s0 += (tl + 16 * u < f.B) ? p0[j][u] : 0.f;
-                        s1 += (tl + 16 * u < f.B) ? p1[j][u] : 0.f;
-                    }
-                    const float cnt = (float)f.B * (float)wg;
-                    m0 = row16_sum(s0) / cnt;
-                    m1 = row16_sum(s1) / cnt;
-                    if (!ok) m0 = __builtin_nanf("");
+                for (int u = 0; u < L0_BPAIRS; ++u) {
+                    s0 += (tl + 16 * u < f.B) ? p0[j][u] : 0.f;
+                    s1 += (tl + 16 * u < f.B) ? p1[j][u] : 0.f;
                 }
-                const float* dzr = (g ? DZ1 : DZ0) + r * f.ldz[g] + f.coff[g][l];
-                const float inv = inv_[j];
-                const bool project = inv < 1.0f / L0_L2_EPS;
-                float dv[L0_NK];
-                float dot = 0.f;
-#pragma unroll
-                for (int k = 0; k < L0_NK; ++k) {
-                    dv[k] = 0.f;
-                    if (16 * k < wmax) {
-                        float d = dzr[min(tl + 16 * k, wg - 1)];
-                        if (has_bn) d = rstd_[j] * (d - m0 - xh[j][k] * m1);
-                        if (!last) d = yv[j][k] > 0.f ? d : 0.f;
-                        if (tl + 16 * k >= wg) d = 0.f;
-                        dv[k] = d;
-                        dot += d * yv[j][k];
-                    }
+                const float cnt = (float)f.B * (float)(g ? w1 : w0);
+                s0 = row16_sum(s0) / cnt;
+                s1 = row16_sum(s1) / cnt;
+                if (!ok) s0 = __builtin_nanf("");
+                if (tl == 0 && it < RB * G) {
+                    M01[it * 2] = s0;
+                    M01[it * 2 + 1] = s1;
                 }
-                dot = row16_sum(dot);
+            }
+        }
+        // ---- BatchNorm / ReLU / l2-normalise backward of my rows -> dU (each team reads back only its own means)
 #pragma unroll
-                for (int k = 0; k < L0_NK; ++k) {
-                    const int c = tl + 16 * k;
-                    if (16 * k < wmax && c < wg && it < RB * G) {
-                        const float v = project ? inv * (dv[k] - yv[j][k] * dot) : inv * dv[k];
-                        DU[r * ct + c0gg + c] = r < nrows ? v : 0.f;
-                    }
+        for (int j = 0; j < ITEMS; ++j) {
+            const int it = team + j * L0_TEAMS;
+            const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+            const int node = min(r0 + r, N - 1);
+            const long row = (long)b * N + node;
+            const int wg = g ? w1 : w0, c0gg = g ? w0 : 0;
+            const float* yp = last ? f.Z[g] + row * f.ldz[g] + f.coff[g][l] : f.Y[l] + row * ct + c0gg;
+            const float* xp = f.Z[g] + row * f.ldz[g] + f.coff[g][l];
+            float yv[L0_NK], xh[L0_NK];
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                const int c = min(tl + 16 * k, wg - 1);
+                yv[k] = yp[c];
+                xh[k] = xp[c];
+            }
+            const float inv = f.invn[l][row * G + g];
+            const float rstd = has_bn ? f.stats[l][((long)node * G + g) * 2 + 1] : 1.f;
+            const float m0 = has_bn ? M01[min(it, RB * G - 1) * 2] : 0.f;
+            const float m1 = has_bn ? M01[min(it, RB * G - 1) * 2 + 1] : 0.f;
+            const float* dzr = (g ? DZ1 : DZ0) + r * f.ldz[g] + f.coff[g][l];
+            const bool project = inv < 1.0f / L0_L2_EPS;
+            float dv[L0_NK];
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                dv[k] = 0.f;
+                if (16 * k < wmax) {
+                    float d = dzr[min(tl + 16 * k, wg - 1)];
+                    if (has_bn) d = rstd * (d - m0 - xh[k] * m1);
+                    if (!last) d = yv[k] > 0.f ? d : 0.f;
+                    if (tl + 16 * k >= wg) d = 0.f;
+                    dv[k] = d;
+                    dot += d * yv[k];
+                }
+            }
+            dot = row16_sum(dot);
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                const int c = tl + 16 * k;
+                if (16 * k < wmax && c < wg && it < RB * G) {
+                    const float v = project ? inv * (dv[k] - yv[k] * dot) : inv * dv[k];
+                    DU[r * ct + c0gg + c] = r < nrows ? v : 0.f;
                 }
             }
         }
@@ -1323,22 +1348,34 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
         L0B_STAMP(8 + 8 * (L - 1 - l));
         // bias gradients: column sums of dU over my rows
         {
-            float* SB = EXT;
+            // eight row groups in parallel, added in row order
+            float* SB = EXT + RB * 4;
+            float* SB8 = SB + ((ct + 3) & ~3);             // [8][ct]
+            constexpr int RG = RB / 8;
+            for (int e = tid; e < 8 * ct; e += L0_NT) {
+                const int grp = e / ct, c = e - grp * ct;
+                float t = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < RG; ++rr) t += DU[(grp * RG + rr) * ct + c];
+                SB8[e] = t;
+            }
+            __syncthreads();
             for (int c = tid; c < ct; c += L0_NT) {
                 float t = 0.f;
-                for (int r = 0; r < RB; ++r) t += DU[r * ct + c];
+#pragma unroll
+                for (int grp = 0; grp < 8; ++grp) t += SB8[grp * ct + c];
                 SB[c] = t;
             }
         }
         l0_write_split(vs_wr(pass, CTt), DU, ct, CTt, a.K8, k8_0, nk8, nrows);
         __syncthreads();
-        if (a.cb[0][l] >= 0) l0_put_compact(gp, a.cb[0][l], EXT, w0);
-        if (G == 2 && a.cb[1][l] >= 0) l0_put_compact(gp, a.cb[1][l], EXT + w0, w1);
+        if (a.cb[0][l] >= 0) l0_put_compact(gp, a.cb[0][l], EXT + RB * 4, w0);
+        if (G == 2 && a.cb[1][l] >= 0) l0_put_compact(gp, a.cb[1][l], EXT + RB * 4 + w0, w1);
         // layer input rows (the left operand of dW, and xhat of the layer below) + this layer's weights: asked for now,
         // they land under the barrier
         // (layer 0: the second stack's input rows do not fit beside the first's — they go to the adjacency block's bytes
         // once the last pass is over)
-        float* XIN0 = EXT + ((ct + 3) & ~3);
+        float* XIN0 = EXT + RB * 4 + 9 * ((ct + 3) & ~3);
         float* XIN1 = l > 0 ? XIN0 + RB * d0 : RA;
         float* W0 = XIN1 + RB * d1;                        // (l > 0 only)
         float* W1 = W0 + ((d0 * w0 + 3) & ~3);
@@ -1346,15 +1383,28 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
             const long rowo = (long)b * N + r0;
             if (l > 0) {
                 // the previous layer's slices of the concat buffers are column slices: row by row
-                for (int e = tid; e < RB * d0; e += L0_NT) {
-                    const int r = e / d0, k = e - r * d0;
-                    XIN0[e] = r < nrows ? f.Z[0][(rowo + r) * f.ldz[0] + f.coff[0][l - 1] + k] : 0.f;
-                }
-                if (G == 2)
-                    for (int e = tid; e < RB * d1; e += L0_NT) {
-                        const int r = e / d1, k = e - r * d1;
-                        XIN1[e] = r < nrows ? f.Z[1][(rowo + r) * f.ldz[1] + f.coff[1][l - 1] + k] : 0.f;
+                {
+                    float xv[ITEMS][L0_NK];
+#pragma unroll
+                    for (int j = 0; j < ITEMS; ++j) {
+                        const int it = team + j * L0_TEAMS;
+                        const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+                        const int dg = g ? d1 : d0;
+                        const float* src = f.Z[g] + (rowo + min(r, nrows - 1)) * f.ldz[g] + f.coff[g][l - 1];
+#pragma unroll
+                        for (int k = 0; k < L0_NK; ++k) xv[j][k] = src[min(tl + 16 * k, dg - 1)];
                     }
+#pragma unroll
+                    for (int j = 0; j < ITEMS; ++j) {
+                        const int it = team + j * L0_TEAMS;
+                        const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+                        const int dg = g ? d1 : d0;
+                        float* dst = (g ? XIN1 : XIN0) + r * dg;
+#pragma unroll
+                        for (int k = 0; k < L0_NK; ++k)
+                            if (tl + 16 * k < dg && it < RB * G) dst[tl + 16 * k] = r < nrows ? xv[j][k] : 0.f;
+                    }
+                }
                 const L0Copy jw[2] = {{W0, f.params + f.st[0].w_off[l], d0 * w0, 0},
                                       {W1, G == 2 ? f.params + f.st[1].w_off[l] : f.params, G == 2 ? d1 * w1 : 0, 0}};
                 l0_copy_many<2, 2>(jw);
@@ -1729,9 +1779,10 @@ bool l0b_geometry(const Level0Bwd& f, L0BGeom& g) {
         const size_t ctp = (size_t)(ct | 1);
         S_((size_t)4 * RB * ctp);
         S_((size_t)RB * ctp + wfl);                                                            // G | staged dW
-        if (l > 0) E_((((size_t)ct + 3) & ~size_t(3)) + (size_t)RB * din + wfl);
+        const size_t ebase = (size_t)RB * 4 + 9 * (((size_t)ct + 3) & ~size_t(3));     // means | bias sums | their 8 row groups
+        if (l > 0) E_(ebase + (size_t)RB * din + wfl);
         else {
-            E_((((size_t)ct + 3) & ~size_t(3)) + (size_t)RB * f.st[0].dims[0]);
+            E_(ebase + (size_t)RB * f.st[0].dims[0]);
             if (G == 2 && (size_t)RB * f.st[1].dims[0] > ra) return false;
         }
     }

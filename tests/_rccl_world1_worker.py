@@ -81,6 +81,19 @@ def main():
     eager_y, eager_loss = ypred.detach().clone(), loss.detach().clone()
     print("eager RCCL step (AVG all-reduce, all_gather_into_tensor x %d, link-norm all-reduce) equals the oracle"
           % n_calls, flush=True)
+    # Drop every reference to the eager step's autograd graph before capturing: its AccumulateGrad nodes belong to the
+    # DEFAULT stream, and a backward pass inside the capture that reuses them synchronises with that (non-capturing)
+    # stream — which invalidates the capture and, on this runtime, segfaults capture_end instead of raising (round 3,
+    # tools/rccl_capture_probe.py: the crash needs no collective at all, only a live graph from another stream).
+    # The parameters' AccumulateGrad nodes live as long as ANY graph that uses them, and every forward re-uses the live
+    # ones: the module's own references (assign_tensor, link_loss are graph outputs) must go too, so that the warm-up
+    # below creates fresh nodes on the capture's side stream.
+    del ypred, loss, yo, lo, inter, P
+    model.assign_tensor = None
+    model.link_loss = None
+    model._last_save = None
+    import gc
+    gc.collect()
 
     # ---- 3: the whole step, collectives included, in one hipGraph
     side = torch.cuda.Stream(device)

@@ -43,16 +43,11 @@ def test_rccl_world1_collectives_and_captured_step():
 
 def test_rccl_world1_sync_bn_collectives_eager_and_captured():
     """The same with sync-BN: the eager step (eight all_gather_into_tensor through the library's callback + the
-    link-normaliser all-reduce, all on RCCL) must equal the oracle.  CAPTURING that step is recorded, not required: at
-    ONE rank RCCL turns an all-gather into a device-to-device copy, and a copy node inside a hipGraph is the known-bad
-    construct of this runtime (memset / memcpy nodes replay garbage or crash at instantiate on ROCm
-    7.2) — round 3 observed a host segfault in exactly this capture.  With two or more ranks the collective is a kernel;
-    that configuration has not run anywhere yet."""
+    link-normaliser all-reduce, all on RCCL) must equal the oracle, and the step captured WITH those collectives inside
+    must replay it.  (Round 3: a host segfault in capture_end first looked like RCCL's doing; tools/rccl_capture_probe.py
+    showed it needs no collective at all — a live autograd graph from another stream is enough — see the worker.)"""
     r = _rccl_world1("sync")
-    assert "eager RCCL step" in r.stdout and "equals the oracle" in r.stdout, r.stdout[-3000:] + "\n" + r.stderr[-6000:]
-    if r.returncode != 0:
-        pytest.xfail(f"sync-BN all-gathers captured at world size 1: child exited with {r.returncode} "
-                     "(single-rank all-gather = device copy node in the graph)")
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-6000:]
     assert "RCCL world-1 run complete (sync)" in r.stdout, r.stdout
 
 
