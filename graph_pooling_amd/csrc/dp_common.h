@@ -36,6 +36,20 @@ __device__ inline void dev_err_raise(int* word, int bit) {
 }
 #endif
 
+// ----------------------------------------------------------------- workgroup barrier for LDS hazards only
+// __syncthreads() is a workgroup-scope fence: while global stores are in flight hipcc puts `s_waitcnt vmcnt(0)` in
+// front of its s_barrier, so every barrier of a kernel that streams saves to global memory also pays a store round trip
+// (~1-2k cycles).  Where the barrier only orders LDS traffic between the waves of the workgroup, this form waits for
+// the LDS counter alone and leaves the stores flying.  NOT a release of global data to anyone.
+#ifdef __HIPCC__
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0) only
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#endif
+
 // ----------------------------------------------------------------- cross-lane reductions on DPP
 // __shfl_xor compiles to ds_bpermute_b32 (an LDS-pipe round trip per step); these run in the VALU.  A DPP row is 16
 // lanes: two quad permutes, then the half-row and the row mirror, leave the row's total in every lane.  The wave

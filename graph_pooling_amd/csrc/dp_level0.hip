@@ -562,7 +562,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         for (long i = (long)wid * per + tid; i < end; i += L0_NT) zp[i] = make_uint4(0, 0, 0, 0);
     }
     if (__any(bad) && lane == 0) sflag[2] = 1;
-    __syncthreads();
+    lds_barrier();
     L0_STAMP(3);
     const bool blk_bad = sflag[2] != 0;
     if (blk_bad && tid == 0) {
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         l0_mma<false, false>(g ? X0s1 : X0s0, g ? din0_1 : din0_0, g ? W0s1 : W0s0, dout, RB, dout, g ? din0_1 : din0_0,
                              [&](int r, int c, float v) { PT[r * ct + c0 + c] = v; }, g * 3);
     }
-    __syncthreads();
+    lds_barrier();
     L0_STAMP(5);
     const int k8_0 = r0 / 8;
     const int nk8 = min(rb == a.T - 1 ? a.K8 - k8_0 : RB / 8, a.K8 - k8_0);
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
             l0_copy_in<4>(Wn0, f.params + f.st[0].w_off[l + 1], wn0);
             if (G == 2) l0_copy_in<4>(Wn1, f.params + f.st[1].w_off[l + 1], wn1);
         }
-        __syncthreads();
+        lds_barrier();
         L0_STAMP(9 + 8 * l);
         // tail: + bias, l2-normalise, save, BatchNorm partials — one 16-lane team per (row, group); y also goes to the
         // layer's slice of the LDS activation rows (BatchNorm rewrites it in place after the exchange)
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         if (last) break;
         // ---- apply_bn: every graph's partials of my node indices (grid barrier), then x = (relu(y) - mu) * rstd
         if (f.bn) ok = l0_barrier<true>(a, b, sflag, ep) && ok;
-        else __syncthreads();
+        else lds_barrier();
         L0_STAMP(11 + 8 * l);
         const int ctn = f.st[0].dims[l + 2] + (G == 2 ? f.st[1].dims[l + 2] : 0);
         float* PTn = Wn1 + ((wn1 + 3) & ~3);               // behind the weights (which sit behind the reduce slots)
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         L0_STAMP(12 + 8 * l);
         // ---- P_{l+1} = [x_e W_e | x_a W_a] of my rows and its split
         for (int g = 0; g < G; ++g) {
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
             l0_mma<false, false>((g ? ACT1 : ACT0) + f.coff[g][l], f.ldz[g], g ? Wn1 : Wn0, dout, RB, dout, din,
                                  [&](int r, int c, float v) { PTn[r * ctn + c0 + c] = v; }, g * 3);
         }
-        __syncthreads();
+        lds_barrier();
         L0_STAMP(13 + 8 * l);
         {
             const int CTn = (ctn + 15) / 16;
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         L0_STAMP(15 + 8 * l);
         ct = ctn;
     }
-    __syncthreads();                                       // the last layer's rows are in ACT0 / ACT1
+    lds_barrier();                                       // the last layer's rows are in ACT0 / ACT1
 
     const int K = f.K, D = f.ldz[0];
     float* XP = SCR;                                       // partial X' [K][D] | A' [K][K] (after the A^T S pass)
@@ -792,13 +792,13 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         float* SL = TL + RB * K;                           // [RB][K]  logits, then S rows
         float* WP = SCR;                                   // [K][Da]  (the reduce area is free now)
         l0_copy_in<4>(WP, f.params + f.wp_off, K * Da);
-        __syncthreads();
+        lds_barrier();
         L0_STAMP(40);
         {
             const float* bp = BIAS + 2 * DP_MAX_LAYERS * 64;
             l0_mma<false, true>(ACT1, Da, WP, Da, RB, K, Da, [&](int r, int c, float v) { SL[r * K + c] = v + bp[c]; });
         }
-        __syncthreads();
+        lds_barrier();
         L0_STAMP(41);
         for (int r = team; r < RB; r += L0_TEAMS) {
             const int node = r0 + r;
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         L0_STAMP(42);
         l0_write_split(vs_wr(L, CTk), SL, K, CTk, a.K8, k8_0, nk8, nrows);
         L0_STAMP(43);
@@ -851,12 +851,12 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
                 l0_stage_commit<MI>(atq, Alds, a.ldp, f.pk_ld, nrows, seg);
             }
         }
-        __syncthreads();
+        lds_barrier();
         L0_STAMP(45);
         // ------------------------------------------------------------------ T = A^T S (my rows), partial X', A'
         l0_aggregate<MI>(a, Alds, exact, Acols, 1, N, nrows, vs_rd(L, CTk), CTk, SCR, ctpk, rot);
         L0_STAMP(46);
-        __syncthreads();
+        lds_barrier();
         L0_STAMP(47);
         for (int r = team; r < RB; r += L0_TEAMS) {
             const long row = (long)b * N + min(r0 + r, N - 1);
@@ -871,13 +871,13 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         L0_STAMP(48);
         float* AP = XP + K * D;
         l0_mma<true, false>(SL, K, ACT0, D, K, D, RB, [&](int i, int j, float v) { XP[i * D + j] = v; });
         l0_mma<true, false>(TL, K, SL, K, K, K, RB, [&](int i, int j, float v) { AP[i * K + j] = v; }, 4);
         for (int e = K * D + K * K + tid; e < a.epad; e += L0_NT) XP[e] = 0.f;
-        __syncthreads();
+        lds_barrier();
         L0_STAMP(49);
         {
             const ScBuf xpb = sc_buf(f.xpart + ((long)b * a.T + rb) * a.epad, (size_t)a.epad * 4);
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
                 MI_[grp * f.rw + c] = bi;
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (int c = tid; c < f.rw; c += L0_NT) {
             float best = -INFINITY;
             int bi = -1;
@@ -990,13 +990,13 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         }
     }
     // ------------------------------------------------------------------ the last workgroup to finish cleans up
-    __syncthreads();
+    lds_barrier();
     L0_STAMP(52);
     if (tid == 0) {
         const int old = ag_add(f.bar + BAR_DONE, 1);
         sflag[3] = old == (int)gridDim.x - 1;
     }
-    __syncthreads();
+    lds_barrier();
     if (sflag[3]) {
         const int gflag = ag_ld(f.bar + BAR_GFLAG);
         if (tid < 64) f.pk_flag[tid] = tid == 0 ? gflag : 0;
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
     };
     auto vs_rd = [&](int pass, int CTt) { return f.vs + a.vs_off[pass] + (long)b * 3 * CTt * a.K8 * 128; };
     bool ok = true;
-    __syncthreads();
+    lds_barrier();
 
     // my rows of dZe (the max-readout scatter of the head's backward) start the running gradient
     if (G == 2 && K > 0) {
@@ -1162,13 +1162,13 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                                     {DZ0, f.dZe + rowo * D, nrows * D, RB * D}};
             l0_copy_many<6, 2>(jobs);
         }
-        __syncthreads();
+        lds_barrier();
         L0B_STAMP(1);
         l0_mma<false, false>(SL, K, DXN, D, RB, D, K, [&](int r, int j, float v) { DZ0[r * D + j] += v; });
         l0_mma<false, true>(ZL, D, DXN, D, RB, K, D, [&](int r, int i, float v) { DS[r * K + i] = v; }, 2);
         l0_mma<false, true>(SL, K, DAN, K, RB, K, K, [&](int r, int i, float v) { VL[r * K + i] = v; }, 4);
         l0_mma<false, false>(TL, K, DAN, K, RB, K, K, [&](int r, int i, float v) { DS2[r * K + i] = v; }, 6);
-        __syncthreads();
+        lds_barrier();
         L0B_STAMP(2);
         l0_write_split(vs_wr(0, CTk), VL, K, CTk, a.K8, k8_0, nk8, nrows);
         {
@@ -1183,11 +1183,11 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                 l0_stage_commit<MI>(q, Alds, a.ldp, f.pk_ld, nrows, seg);
             }
         }
-        __syncthreads();
+        lds_barrier();
         L0B_STAMP(3);
         // ------------------------------------------------------------------ dS += A V;  softmax backward
         l0_aggregate<MI>(a, Alds, exact, Arows, N, 1, nrows, vs_rd(0, CTk), CTk, SCR, ctpk, rot);
-        __syncthreads();
+        lds_barrier();
         L0B_STAMP(4);
         float* DLOG = DS;                                  // in place, row by row
         for (int r = team; r < RB; r += L0_TEAMS) {
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                 if (c < K) DLOG[r * K + c] = r < nrows ? sv[k] * (dv[k] - dot) : 0.f;
             }
         }
-        __syncthreads();
+        lds_barrier();
         L0B_STAMP(5);
         // assign_pred: dWp = dlog^T Za, dbp = column sums, dZa = dlog Wp
         {
@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
             const L0Copy jobs[2] = {{ZAL, f.Z[1] + ((long)b * N + r0) * Da, nrows * Da, RB * Da},
                                     {WP, f.params + f.wp_off, K * Da, 0}};
             l0_copy_many<2, 3>(jobs);
-            __syncthreads();
+            lds_barrier();
             l0_mma<true, false>(DLOG, K, ZAL, Da, K, Da, RB, [&](int i, int j, float v) { STG[i * Da + j] = v; });
             l0_mma<false, false>(DLOG, K, WP, Da, RB, Da, K, [&](int r, int j, float v) { DZ1[r * Da + j] = v; }, 4);
             float* SB = STG + ((K * Da + 3) & ~3);
@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                 for (int r = 0; r < RB; ++r) t += DLOG[r * K + c];
                 SB[c] = t;
             }
-            __syncthreads();
+            lds_barrier();
             l0_put_compact(gp, a.cwp, STG, K * Da);
             if (a.cbp >= 0) l0_put_compact(gp, a.cbp, SB, K);
         }
@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
         if (G == 2)
             for (int e = tid; e < RB * Da; e += L0_NT) DZ1[e] = 0.f;
     }
-    __syncthreads();
+    lds_barrier();
 
     // ------------------------------------------------------------------ the GraphConv layers, last to first
     constexpr int ITEMS = (RB * 2 + L0_TEAMS - 1) / L0_TEAMS;
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         L0B_STAMP(8 + 8 * (L - 1 - l));
         // bias gradients: column sums of dU over my rows
         {
@@ -1359,7 +1359,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                 for (int rr = 0; rr < RG; ++rr) t += DU[(grp * RG + rr) * ct + c];
                 SB8[e] = t;
             }
-            __syncthreads();
+            lds_barrier();
             for (int c = tid; c < ct; c += L0_NT) {
                 float t = 0.f;
 #pragma unroll
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
             }
         }
         l0_write_split(vs_wr(pass, CTt), DU, ct, CTt, a.K8, k8_0, nk8, nrows);
-        __syncthreads();
+        lds_barrier();
         if (a.cb[0][l] >= 0) l0_put_compact(gp, a.cb[0][l], EXT + RB * 4, w0);
         if (G == 2 && a.cb[1][l] >= 0) l0_put_compact(gp, a.cb[1][l], EXT + RB * 4 + w0, w1);
         // layer input rows (the left operand of dW, and xhat of the layer below) + this layer's weights: asked for now,
@@ -1425,14 +1425,14 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                 l0_stage_commit<MI>(q, Alds, a.ldp, f.pk_ld, nrows, seg);
             }
             have_at = true;
-            __syncthreads();
+            lds_barrier();
         } else {
             ok = l0_barrier<false>(a, b, sflag, ep) && ok;
         }
         L0B_STAMP(10 + 8 * (L - 1 - l));
         // ---- G = A^T dU (my rows), summed in place into the first reduce slot
         l0_aggregate<MI>(a, Alds, exact, Acols, 1, N, nrows, vs_rd(pass, CTt), CTt, SCR, ctp, rot);
-        __syncthreads();
+        lds_barrier();
         L0B_STAMP(11 + 8 * (L - 1 - l));
         float* Gt = SCR;                                   // [RB][ctp]
         for (int e = tid; e < RB * ct; e += L0_NT) {
@@ -1441,12 +1441,12 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
             const float v = (SCR[o] + SCR[RB * ctp + o]) + (SCR[2 * RB * ctp + o] + SCR[3 * RB * ctp + o]);
             Gt[o] = r < nrows ? v : 0.f;
         }
-        __syncthreads();
+        lds_barrier();
         L0B_STAMP(12 + 8 * (L - 1 - l));
         if (l == 0 && G == 2) {
             const L0Copy jx[1] = {{XIN1, f.x0[1] + ((long)b * N + r0) * d1, nrows * d1, RB * d1}};
             l0_copy_many<1, 4>(jx);
-            __syncthreads();
+            lds_barrier();
         }
         // ---- dW = x_in^T G  (staged behind the first slot);  dx_in += G W^T
         float* STG0 = SCR + RB * ctp;
@@ -1462,7 +1462,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                 l0_mma<false, true>(Gt + w0, ctp, W1, w1, RB, d1, w1, [&](int r, int k, float v) { dz1[r * Da + k] += v; }, 7);
             }
         }
-        __syncthreads();
+        lds_barrier();
         L0B_STAMP(13 + 8 * (L - 1 - l));
         l0_put_compact(gp, a.cw[0][l], STG0, d0 * w0);
         if (G == 2) l0_put_compact(gp, a.cw[1][l], STG1, d1 * w1);
@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
             L0B_STAMP(14 + 8 * (L - 1 - l));
             ok = l0_barrier<true>(a, b, sflag, ep) && ok;
         } else {
-            __syncthreads();
+            lds_barrier();
         }
         L0B_STAMP(15 + 8 * (L - 1 - l));
     }
@@ -1532,13 +1532,13 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     L0B_STAMP(41);
     if (tid == 0) {
         const int old = ag_add(f.bar + BAR_DONE, 1);
         sflag[3] = old == (int)gridDim.x - 1;
     }
-    __syncthreads();
+    lds_barrier();
     if (sflag[3]) {
         for (int g = tid; g < f.B; g += L0_NT) ag_st(f.bar + BAR_GRAPH0 + g * BAR_GSTRIDE, 0);
         if (tid == 0) {

@@ -47,16 +47,16 @@ __device__ inline float team16_sum(float v) {
 // block-wide reductions over 256 threads (red: 8 floats of LDS)
 __device__ inline float block_max(float v, float* red) {
     v = wave64_max(v);
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 __device__ inline float block_sum(float v, float* red) {
     v = wave64_sum(v);
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     return red[0] + red[1] + red[2] + red[3];
 }
 
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_set2set_fwd(S2SFwdArgs a) {
         emb = le;
         lde = d;
     }
-    __syncthreads();
+    lds_barrier();
     const int tl = tid & 15, team = tid >> 4;
     // per-thread gate biases (were two global loads per gate per step, at the head of every step's critical path)
     constexpr int GPT = 4;                            // gates per thread: 4d <= 1024
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_set2set_fwd(S2SFwdArgs a) {
             for (int k = 0; k < d; ++k) acc2 += W[(d + k) * GS + g] * r[k];
             gates[g] = acc + acc2;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- LSTM cell (gate order i, f, g, o)
         for (int j = tid; j < d; j += 256) {
             const float ig = sigmoidf_(gates[j]), fg = sigmoidf_(gates[d + j]);
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_set2set_fwd(S2SFwdArgs a) {
                 a.H[((long)b * n + t) * d + j] = hn;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- e = emb . h  (all n rows, padded rows included — set2set.py:50-51)
         float lmax = -INFINITY;
         for (int row = team; row < n; row += 16) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_set2set_fwd(S2SFwdArgs a) {
             al[row] = v;
             if (a.Aw) a.Aw[((long)b * n + t) * n + row] = v;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- r = sum_n a[n] emb[n]
         for (int j0 = 0; j0 < d; j0 += 64) {
             const int j = j0 + (tid & 63), part = tid >> 6;
@@ -189,9 +189,9 @@ __global__ __launch_bounds__(256) void k_set2set_fwd(S2SFwdArgs a) {
                 for (int row = part; row < n; row += 4) s += al[row] * emb[(long)row * lde + j];
             }
             rpart[part * 64 + (tid & 63)] = s;
-            __syncthreads();
+            lds_barrier();
             if (part == 0 && j < d) r[j] = rpart[tid] + rpart[64 + tid] + rpart[128 + tid] + rpart[192 + tid];
-            __syncthreads();
+            lds_barrier();
         }
     }
     // ---- out = relu(Wp [h, r] + bp)
@@ -250,13 +250,13 @@ __global__ __launch_bounds__(256) void k_set2set_bwd(S2SBwdArgs a) {
         a.DPRE[(long)b * d + j] = v;
         dc[j] = 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     for (int k = tid; k < 2 * d; k += 256) {
         float s = 0.f;
         for (int j = 0; j < d; ++j) s += a.Wp[(long)j * 2 * d + k] * dg[j];
         if (k < d) dh[k] = s; else dr[k - d] = s;
     }
-    __syncthreads();
+    lds_barrier();
     const float* emb = a.emb_in_lds ? le : a.emb + (long)b * n * a.lde;
     const int lde = a.emb_in_lds ? d : a.lde;
     const int tl = tid & 15, team = tid >> 4;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_set2set_bwd(S2SBwdArgs a) {
             if (tid + 256 * i < n) lat[tid + 256 * i] = at_c[i];
         // ---- r_t = sum a emb:  da = emb . dr ;  de = a * (da - sum a da)
         for (int j = tid; j < d; j += 256) a.DR[((long)b * n + t) * d + j] = dr[j];
-        __syncthreads();
+        lds_barrier();
         prefetch(t - 1);
         float lsum = 0.f;
         for (int row = team; row < n; row += 16) {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_set2set_bwd(S2SBwdArgs a) {
                 a.DE[((long)b * n + t) * n + row] = v;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- e = emb . h_t:  dh += sum_n de[n] emb[n]
         for (int j0 = 0; j0 < d; j0 += 64) {
             const int j = j0 + (tid & 63), part = tid >> 6;
@@ -321,9 +321,9 @@ __global__ __launch_bounds__(256) void k_set2set_bwd(S2SBwdArgs a) {
                 for (int row = part; row < n; row += 4) s += de[row] * emb[(long)row * lde + j];
             }
             rpart[part * 64 + (tid & 63)] = s;
-            __syncthreads();
+            lds_barrier();
             if (part == 0 && j < d) dh[j] += rpart[tid] + rpart[64 + tid] + rpart[128 + tid] + rpart[192 + tid];
-            __syncthreads();
+            lds_barrier();
         }
         // ---- LSTM cell backward
         if (tid < d) {
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void k_set2set_bwd(S2SBwdArgs a) {
             o[j] = d_i; o[d + j] = d_f; o[2 * d + j] = d_g; o[3 * d + j] = d_o;
             dc[j] = dct * fg;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- [dh_{t-1}, dr_{t-1}] = Wt dg   (h_{t-1} and r_{t-1} feed only this step's LSTM)
         for (int k = tid; k < 2 * d; k += 256) {
             float s = 0.f, s2 = 0.f;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_set2set_bwd(S2SBwdArgs a) {
             s += s2;
             if (k < d) dh[k] = s; else dr[k - d] = s;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 

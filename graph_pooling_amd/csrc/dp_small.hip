@@ -335,8 +335,9 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
     float* IV = DX + n * din;          // [n] 1/||u||
     float* M0 = IV + n;                // [n]
     float* M1 = M0 + n;                // [n]
-    float* DB = M1 + n;                // [dout] column sums of dU (bias gradient), LDS atomics
-    float* RS = DB + dout;             // [n] BN rstd of this layer
+    float* DB = M1 + n;                // [dout] column sums of dU (bias gradient)
+    float* DBW = DB + dout;            // [16 waves][dout] their per-wave partials
+    float* RS = DBW + 16 * dout;       // [n] BN rstd of this layer
     float* DA = RS + n;                // [n][n] running dA' (when the level's adjacency gradient is wanted)
     float* PP = DA + (a.dadj ? n * n : 0);   // [B][n][2] staged BN-backward partials
     const int tl = tid & 15, team = tid >> 4;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
         sm_dma(XH, n * dout, [&](int e) { return a.xhat + ((long)b * n + a.qdout.quot(e)) * a.ldxh + a.qdout.rem(e); });
     sm_dma(IV, n, [&](int e) { return a.invn + (long)b * n + e; });
     if (a.has_bn) sm_dma(PP, a.B * n * 2, [&](int e) { return a.part2 + e; });
-    for (int i = tid; i < dout; i += NT) DB[i] = 0.f;
+    for (int i = tid; i < 17 * dout; i += NT) DB[i] = 0.f;     // DB and DBW
     SM_STAMP(1, 8);
     __syncthreads();
     SM_STAMP(1, 9);
@@ -405,19 +406,25 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
                 v = project ? inv * (d - P[r * dout + c] * dot) : inv * d;
                 dU[r * dout + c] = v;
             }
-            // bias gradient = column sums of dU: the four rows of this wave first, then one LDS float atomic per
-            // wave and column (a serial column walk after the barrier held a whole wave back for ~4.5k cycles)
+            // bias gradient = column sums of dU: the four rows of this wave first, then one partial per wave and
+            // column, summed in wave order below (LDS float atomics here made the bias gradients differ in the last
+            // place from run to run; a serial column walk held a whole wave back for ~4.5k cycles)
             if (dbb) {
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
-                if ((tid & 63) < 16 && c < dout) atomicAdd(&DB[c], v);
+                if ((tid & 63) < 16 && c < dout) DBW[(tid >> 6) * dout + c] += v;
             }
         }
     }
     __syncthreads();
     SM_STAMP(1, 2);
     if (dbb)
-        for (int c = tid; c < dout; c += NT) dbb[c] = DB[c];
+        for (int c = tid; c < dout; c += NT) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) t += DBW[w * dout + c];     // wave order: bit-reproducible
+            dbb[c] = t;
+        }
     SM_STAMP(1, 10);
     lds_mma<true, false>(A, n, dU, dout, n, dout, n, [&](int m, int c, float v) {
         G[m * dout + c] = a.add_self ? v + dU[m * dout + c] : v;
@@ -591,7 +598,7 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
         }
     }
     SM_STAMP(0, 8);
-    __syncthreads();
+    __syncthreads();                       // (drains the LDS-DMA burst: vmcnt)
     SM_STAMP(0, 9);
 
     int wo = 0, bo = 0;
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
         const float* BL = BI + bo;
         // P = X W
         lds_mma2<false, false>(X, din, W, dout, n, dout, din, [&](int r, int c, float v) { P[r * dout + c] = v; });
-        __syncthreads();
+        lds_barrier();
         SM_STAMP(0, 10 + 6 * l);
         // U = A P (+ P) + bias
         lds_mma2<false, false>(A, n, P, dout, n, dout, n, [&](int r, int c, float v) {
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
             U[r * dout + c] = v + BL[c];
         });
         if (l == 2) SM_STAMP(0, 30);
-        __syncthreads();
+        lds_barrier();
         SM_STAMP(0, 11 + 6 * l);
         // l2-normalise rows -> y (kept in U), saved output, BN partials of relu(y)
         const bool stats = !last && a.bn;
@@ -688,7 +695,7 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
                 rs[r] = 1.f;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // next layer's input: x = (relu(y) - mu) * rstd, also this layer's slice of the concat buffer
         for (int r = team; r < n; r += NTEAMS)
             for (int k = tl; k < dout; k += 16) {
@@ -696,7 +703,7 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
                 X[r * dout + k] = v;
                 a.Ze[((long)b * n + r) * a.ldz + a.coff[l] + k] = v;
             }
-        __syncthreads();
+        lds_barrier();
         SM_STAMP(0, 15 + 6 * l);
         wo += din * dout;
         bo += dout;
@@ -753,6 +760,7 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
     float* M0 = P + n * a.omax;            // [n]
     float* M1 = M0 + n;                    // [n]
     float* DB = M1 + n;                    // [omax]
+    float* DBW = DB + a.omax;              // [16 waves][omax] per-wave partials of the bias sums
     const int tl = tid & 15, team = tid >> 4;
     const int NT = blockDim.x, NTEAMS = blockDim.x >> 4;
 
@@ -784,7 +792,7 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
     }
     if (a.dadj)
         for (int i = tid; i < n * n; i += NT) DA[i] = 0.f;
-    __syncthreads();
+    __syncthreads();                       // (drains the LDS-DMA burst: vmcnt)
 
     int wo_end = a.wtot;
     int nbar = 0;
@@ -800,7 +808,7 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
         const float* Yl = last ? ZE + a.coff[l] : YS + l * n * a.omax;   // normalised output
         const int ldy = last ? D : dout;
         float* dx = DZ + a.coff[l];                               // gradient w.r.t. this layer's output (ld D)
-        for (int i = tid; i < dout; i += NT) DB[i] = 0.f;
+        for (int i = tid; i < 16 * dout; i += NT) DBW[i] = 0.f;
         if (has_bn) {
             // BN backward needs, per node index, the sums over ALL graphs of (dx, dx * xhat)
             float* part_l = a.part + (long)l * a.B * n * 2;
@@ -844,7 +852,7 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- dU = normalise^T relu^T bn^T dx, one team per row (uniform trip count: the bias sums reduce across
         // the four row teams of a wave)
         float* dbb = a.b_off[l] >= 0 ? a.slabs + (long)b * a.slab_stride + a.b_off[l] : nullptr;
@@ -882,13 +890,18 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
                 if (dbb && 16 * k < dout) {
                     v += __shfl_xor(v, 16, 64);
                     v += __shfl_xor(v, 32, 64);
-                    if ((tid & 63) < 16 && c < dout) atomicAdd(&DB[c], v);
+                    if ((tid & 63) < 16 && c < dout) DBW[(tid >> 6) * dout + c] += v;   // one partial per wave, no atomics
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (dbb)
-            for (int c = tid; c < dout; c += NT) dbb[c] = DB[c];
+            for (int c = tid; c < dout; c += NT) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) t += DBW[w * dout + c];   // wave order: bit-reproducible
+                dbb[c] = t;
+            }
         // G = A^T dU (+ dU);  P = X W (for dA)
         lds_mma2<true, false>(A, n, dU, dout, n, dout, n, [&](int m, int c, float v) {
             G[m * dout + c] = a.add_self ? v + dU[m * dout + c] : v;
@@ -896,7 +909,7 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
         if (a.dadj)
             lds_mma2<false, false>(Xl, ldx, W, dout, n, dout, din, [&](int m, int c, float v) { P[m * dout + c] = v; },
                                   ((n + 15) / 16) * ((dout + 15) / 16));
-        __syncthreads();
+        lds_barrier();
         // dW = X^T G -> this graph's slab
         {
             float* dWb = a.slabs + (long)b * a.slab_stride + a.w_off[l];
@@ -915,7 +928,7 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
         // dA += dU P^T
         if (a.dadj)
             lds_mma2<false, true>(dU, dout, P, dout, n, n, dout, [&](int r, int m, float v) { DA[r * n + m] += v; }, 2);
-        __syncthreads();
+        lds_barrier();
     }
     if (a.dadj)
         for (int i = tid; i < n * n; i += NT) a.dadj[(long)b * n * n + i] = DA[i];
@@ -926,7 +939,7 @@ size_t small_lds_floats_fwd(int B, int n, int din, int dout) {
            (size_t)B * n * 2 + 16;
 }
 size_t small_lds_floats_bwd(int B, int n, int din, int dout) {
-    return 2 * (size_t)n * n + 2 * (size_t)n * din + (size_t)din * dout + 4 * (size_t)n * dout + 4 * n + dout +
+    return 2 * (size_t)n * n + 2 * (size_t)n * din + (size_t)din * dout + 4 * (size_t)n * dout + 4 * n + 17 * (size_t)dout +
            (size_t)B * n * 2 + 16;
 }
 
@@ -993,7 +1006,7 @@ static size_t small_level_lds_bwd(int B, int n, const int* dims, int L, bool dad
         D += dims[l + 1];
     }
     return (size_t)n * n * (dadj ? 2 : 1) + (size_t)n * dims[0] + 2 * (size_t)n * D + (size_t)(L - 1) * n * omax + wtot +
-           2 * (size_t)L * n + 3 * (size_t)n * omax + 2 * n + omax + 64 + 16;
+           2 * (size_t)L * n + 3 * (size_t)n * omax + 2 * n + 17 * (size_t)omax + 64 + 16;
 }
 static int device_cus() {
     static std::atomic<int> cus[64];

@@ -116,7 +116,9 @@ def main():
     torch.testing.assert_close(gy, eager_y, rtol=0, atol=0)
     torch.testing.assert_close(gl, eager_loss, rtol=0, atol=0)
     for k, p in model.named_parameters():
-        if k.endswith(".bias"):
+        if sync_bn and k.endswith(".bias"):
+            # sync-BN runs level 0 on the per-layer kernels, whose bias sums are float atomics (last-place differences
+            # between any two runs); the persistent kernels of the default mode have none
             torch.testing.assert_close(p.grad, eager[k], rtol=1e-4, atol=1e-7)
         else:
             torch.testing.assert_close(p.grad, eager[k], rtol=0, atol=0, msg=lambda m, k=k: f"{k}: {m}")
