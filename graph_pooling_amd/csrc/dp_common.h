@@ -67,6 +67,16 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_src<0x140, 0xF, true>(0.f, v);      // row_mirror
     return v;
 }
+__device__ __forceinline__ float quad4_sum(float v) {      // total of each aligned group of 4 lanes, in all 4
+    v += dpp_src<0xB1, 0xF, true>(0.f, v);
+    v += dpp_src<0x4E, 0xF, true>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float oct8_sum(float v) {       // ... of 8 lanes (half a DPP row)
+    v = quad4_sum(v);
+    v += dpp_src<0x141, 0xF, true>(0.f, v);      // row_half_mirror
+    return v;
+}
 __device__ __forceinline__ float row16_max(float v) {
     v = fmaxf(v, dpp_src<0xB1, 0xF, true>(v, v));
     v = fmaxf(v, dpp_src<0x4E, 0xF, true>(v, v));

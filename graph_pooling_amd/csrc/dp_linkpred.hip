@@ -27,8 +27,9 @@ __device__ inline float lk_block_sum(float v, float* red) {
 
 // LDS images of S row blocks are [rows][KP] with KW = 16 KT padded columns (zero beyond K) and KP = KW + 2, so the
 // MFMA fragment read (16 rows x 2 k per 32-lane group) touches 32 distinct banks.
+// (force-inlined: as a real call — which hipcc chose for KT >= 12 — its pointers are generic and every access a flat_load)
 template <int KT, int ROWS>
-__device__ inline void lk_stage(const float* Sb, int lds_ld, int r0, int n, int K, float* dst) {
+__device__ __forceinline__ void lk_stage(const float* Sb, int lds_ld, int r0, int n, int K, float* dst) {
     constexpr int KW = KT * 16, KP = KW + 2;
     // loads first, selects and LDS writes after: a select right behind its load makes every load a round trip of
     // its own (the first version: one `s_waitcnt vmcnt(0)` per element, 32 serial round trips in the forward kernel)
@@ -50,7 +51,7 @@ __device__ inline void lk_stage(const float* Sb, int lds_ld, int r0, int n, int 
 
 // P tile of a wave: rows wr*32.., cols wc*16*NJ.. ; acc[mi][ni] are 16x16 tiles
 template <int KT, int NJ>
-__device__ inline void lk_ptile(const float* Sr, const float* Sc, int K, int wr, int wc, int l15, int kq,
+__device__ __forceinline__ void lk_ptile(const float* Sr, const float* Sc, int K, int wr, int wc, int l15, int kq,
                                 lk_f32x4 (&acc)[2][NJ]) {
     constexpr int KP = KT * 16 + 2;
 #pragma unroll
