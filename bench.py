@@ -13,8 +13,12 @@ sharded by graph (weak scaling: 20 graphs per GPU), and the only collective is o
 flat gradient buffer per step.
 
 Rank 0 prints ONE JSON line with the driver's fields plus
-  "roofline":     dominant kernel (the level-0 aggregation pass  U = A · [X W_e | X W_a]), algorithmic bytes
-                  per launch / its average duration measured with HIP events on the launch stream
+  "roofline":     the step's dominant kernel: for the DD-shaped workload the persistent level-0 backward kernel
+                  (k_level0_bwd; its forward twin under "roofline_fwd", the stand-alone aggregation kernel the other
+                  plans use under "roofline_aggregate"), for ER the MFMA-bound pooling product.  Algorithmic bytes
+                  (flops) per launch over the kernel's average duration — `us_per_launch_events` measured in this run
+                  with HIP events on the launch stream, `rocprof_avg_ns` the tracked rocprofv3 figure from profiles/
+                  (frac is priced on the latter when present); `traffic` = PMC bytes from profiles/, not this run
   "cpu_baseline": the CPU oracle (oracle/diffpool_oracle.py, a torch-CPU restatement pinned to the
                   reference by tests/golden) timed on this host on the same workload.
 """
@@ -176,6 +180,79 @@ def step_roofline(w, linkpred, ms_per_step, world=1):
                 adjacency_passes=pf + pb, note="per GPU; HBM 8.0 TB/s, bf16 MFMA 2.5 PFLOP/s dense")
 
 
+def _profiled(kernel, shape):
+    """What profiles/ holds for `kernel` at `shape`: {"rocprof_avg_ns", "traffic_bytes", "source", ...} written by
+    tools/update_pmc_traffic.py from tools/refresh_profiles.sh's rocprofv3 passes (an EARLIER run of this build on a GPU
+    box, not this run) — or {} when the kernel / shape was never profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get("kernels", {}).get(kernel, {}).get(shape, {}) or {}
+    except Exception:              # noqa: BLE001
+        return {}
+
+
+def _roofline(bound, kernel, work, us_events, prof, peak, unit, **extra):
+    """One roofline object.  `work` = algorithmic bytes (or flops) per launch.  Two durations are reported side by side:
+    `us_per_launch_events` — HIP events on the launch stream, measured in THIS run — and `rocprof_avg_ns`, the tracked
+    rocprofv3 --kernel-trace --stats AverageNs of the same kernel at the same shape from profiles/ (null when profiles/
+    has none).  `achieved` / `frac` are priced on the rocprof figure when there is one (so the line can be re-derived
+    from the committed profile), else on the events; `achieved_events` is always the events-based rate."""
+    scale = 1e9 if unit == "GB/s" else 1e12
+    ev = work / (us_events * 1e-6) / scale
+    ns = prof.get("rocprof_avg_ns")
+    ach = work / (ns * 1e-9) / scale if ns else ev
+    return dict(bound=bound, achieved=round(ach, 1), peak=peak, unit=unit, frac=round(ach / peak, 4),
+                traffic=prof.get("traffic_bytes"),
+                traffic_source=("from " + prof["source"] + ", not this run") if prof.get("traffic_bytes") else None,
+                kernel=kernel, us_per_launch_events=round(us_events, 2), rocprof_avg_ns=ns,
+                frac_priced_on="rocprof_avg_ns (profiles/)" if ns else "us_per_launch_events (this run)",
+                achieved_events=round(ev, 1), **extra)
+
+
+def level0_probe(w, model, fwd_bwd, steps=30):
+    """The DD-shaped step's dominant kernels are the two persistent level-0 kernels (dp_level0.hip): k_level0_fwd runs the
+    whole level-0 forward (3 GraphConv layers of both stacks, assign head, X' = S^T Z, A' = S^T A S, readout) and
+    k_level0_bwd its mirror, with each workgroup's bf16 adjacency rows resident in LDS.  Their launches are timed live by
+    the library's own event pairs (dp_profile_level0) over `steps` eager steps of the SAME model and batch.
+
+    Algorithmic bytes per launch: the adjacency passes the kernel stands for —
+    p_f = 2L + 1 forward, p_b = 2(L - 1) + 1 backward — x B x N^2 x 2 bytes (bf16, the element the products multiply;
+    the forward kernel reads the fp32 input once and the backward the bf16 A and A^T copies once: see `traffic`),
+    plus 8 N (D + D_a + K) bytes of activations per graph and direction.  Returns None when the plan did not take
+    the persistent kernels (N < 128, sync-BN, ...)."""
+    from graph_pooling_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    _lib.check(lib.dp_profile_level0(1))
+    for _ in range(steps):
+        fwd_bwd()
+    torch.cuda.synchronize()
+    out = []
+    for which in (0, 1):
+        us, n = C.c_double(0.0), C.c_int(0)
+        _lib.check(lib.dp_profile_level0_read(which, C.byref(us), C.byref(n)))
+        out.append((us.value, n.value))
+    _lib.check(lib.dp_profile_level0(0))
+    if out[0][1] == 0 or out[1][1] == 0:
+        return None
+    B, N, H, L = w["B"], w["N"], w["H"], 3
+    K = int(N * w["ratio"])
+    D, Da = H * L, H * (L - 1) + K
+    act = 8 * N * (D + Da + K) * B
+    shape = f"B{B}_N{N}"
+    res = {}
+    for which, name, passes in ((1, "k_level0_bwd", 2 * (L - 1) + 1), (0, "k_level0_fwd", 2 * L + 1)):
+        us = out[which][0] / out[which][1]
+        alg = passes * B * N * N * 2 + act
+        res[name] = _roofline(
+            "hbm", f"{name}: persistent level-0 {'backward' if which else 'forward'}, one workgroup per (graph, row "
+                   f"block), bf16 adjacency rows resident in LDS", alg, us, _profiled(name, shape), HBM_PEAK_GBS, "GB/s",
+            algorithmic_bytes=alg, adjacency_passes_stood_for=passes, launches_timed=out[which][1],
+            note="latency-bound by construction at B=20: the kernel reads the adjacency from HBM once instead of "
+                 "once per pass, so HBM traffic is a fraction of the algorithmic bytes")
+    return res
+
+
 def roofline_probe(w, device, iters=200):
     """Average duration of the dominant kernel, HIP events on the launch stream: the level-0 adjacency
     aggregation  U[b] = A[b] (N x N) · V[b] (N x C),  C = H_embed + H_assign, exactly as the encoder plan runs it
@@ -220,23 +297,13 @@ def roofline_probe(w, device, iters=200):
     ct, k8 = (Cc + 15) // 16, ((N + 31) // 32) * 4
     fp32_bytes = B * N * N * 4 + 2 * B * N * Cc * 4
     bytes_alg = (B * N * ld * 2 + B * 3 * ct * k8 * 256 + B * N * Cc * 4) if packed else fp32_bytes
-    achieved = bytes_alg / (us * 1e-6) / 1e9
-    traffic = None
-    try:                           # PMC traffic of this kernel at this shape, measured with rocprofv3 (profiles/)
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        key = f"B{B}_N{N}_C{Cc}"
-        traffic = t.get("k_aggregate_packed" if packed else "k_aggregate_fp32", {}).get(key)
-    except Exception:              # noqa: BLE001
-        traffic = None
-    return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                kernel=(f"k_aggregate_wide<{ct}>" if packed and B * ((N + 127) // 128) >= 512
-                        else f"k_aggregate<false,{ct},{32 if B * ((N + 31) // 32) >= 256 else 16},4>")
-                + (" bf16-packed A x 3-plane bf16 V (exact)" if packed else " fp32 panel")
-                + " — level-0 aggregation A·[XW_e|XW_a]",
-                us_per_launch=round(us, 2), algorithmic_bytes=bytes_alg,
-                fp32_equiv={"bytes": fp32_bytes, "GB/s": round(fp32_bytes / (us * 1e-6) / 1e9, 1)})
+    name = "k_aggregate_packed" if packed else "k_aggregate_fp32"
+    return _roofline("hbm", (f"k_aggregate_wide<{ct}>" if packed and B * ((N + 127) // 128) >= 512
+                             else f"k_aggregate<false,{ct},{32 if B * ((N + 31) // 32) >= 256 else 16},4>")
+                     + (" bf16-packed A x 3-plane bf16 V (exact)" if packed else " fp32 panel")
+                     + " — level-0 aggregation A·[XW_e|XW_a]", bytes_alg, us, _profiled(name, f"B{B}_N{N}_C{Cc}"),
+                     HBM_PEAK_GBS, "GB/s", algorithmic_bytes=bytes_alg,
+                     fp32_equiv={"bytes": fp32_bytes, "GB/s": round(fp32_bytes / (us * 1e-6) / 1e9, 1)})
 
 
 def mfma_probe(w, device, iters=50):
@@ -280,21 +347,16 @@ def mfma_probe(w, device, iters=50):
     ct = (K + 15) // 16
     ct = ct if ct <= 8 else (ct + 1) // 2 * 2
     executed = 2.0 * B * N * (((N + 31) // 32) * 32) * ct * 16 * 3
-    tf = alg / (us * 1e-6) / 1e12
-    pmc = None
-    try:                           # MFMA-busy PMC of this kernel at this shape (profiles/r01b_er_pmc_summary.csv)
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pmc = json.load(f).get("mfma_util", {}).get(f"k_aggregate_wide_dma_B{B}_N{N}_K{K}")
-    except Exception:              # noqa: BLE001
-        pmc = None
-    return dict(bound="mfma", achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
-                frac=round(tf / MFMA_BF16_PEAK_TF, 4), traffic=None,
-                kernel=f"k_aggregate_wide_dma<{ct},8>: T = A^T S of the pooling step, bf16-packed A^T x 3-plane bf16 S "
-                       f"(exact), B={B} N={N} K={K}",
-                us_per_launch=round(us, 2), algorithmic_flops=alg,
-                mfma_executed={"flops": executed, "TFLOP/s": round(executed / (us * 1e-6) / 1e12, 1),
-                               "frac_of_bf16_peak": round(executed / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF, 4)},
-                mfma_busy_pmc=pmc)
+    prof = _profiled("k_aggregate_wide_dma", f"B{B}_N{N}_K{K}")
+    r = _roofline("mfma", f"k_aggregate_wide_dma<{ct},8>: T = A^T S of the pooling step, bf16-packed A^T x 3-plane bf16 S "
+                          f"(exact), B={B} N={N} K={K}", alg, us, prof, MFMA_BF16_PEAK_TF, "TFLOP/s",
+                  algorithmic_flops=alg,
+                  mfma_executed={"flops": executed, "TFLOP/s": round(executed / (us * 1e-6) / 1e12, 1),
+                                 "frac_of_bf16_peak": round(executed / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF, 4)},
+                  mfma_busy_pmc=prof.get("mfma_busy"))
+    r["traffic"] = None
+    r["traffic_source"] = None
+    return r
 
 
 def main():
@@ -458,7 +520,14 @@ def main():
                 out["roofline"] = mfma_probe(w, device)
                 out["roofline_hbm"] = roofline_probe(w, device)
             else:
-                out["roofline"] = roofline_probe(w, device)
+                l0 = level0_probe(w, model, fwd_bwd) if w.get("model") != "set2set" else None
+                if l0 is not None:
+                    # the persistent level-0 kernels carry the step: the backward one is the longest kernel of the step
+                    out["roofline"] = l0["k_level0_bwd"]
+                    out["roofline_fwd"] = l0["k_level0_fwd"]
+                    out["roofline_aggregate"] = roofline_probe(w, device)
+                else:
+                    out["roofline"] = roofline_probe(w, device)
             out["roofline"]["step"] = step_roofline(w, args.linkpred, ms)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cpu, w, args.linkpred)

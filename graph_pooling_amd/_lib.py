@@ -70,6 +70,8 @@ _PROTOS = {
     "dp_last_error_string": (C.c_char_p, []),
     "dp_device_error": (_I, [_I]),
     "dp_device_error_describe": (C.c_char_p, [_I]),
+    "dp_profile_level0": (_I, [_I]),
+    "dp_profile_level0_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(_I)]),
     "dp_sizeof_encoder_cfg": (_Z, []),
     "dp_bgemm_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _F, _I, _P]),
     "dp_bgemm_split_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _P]),

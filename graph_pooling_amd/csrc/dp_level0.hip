@@ -31,6 +31,8 @@
 // bf16 MFMA with fp32 accumulation, every product exact; a graph whose adjacency is NOT bf16-exact takes an fp32 MFMA
 // loop that reads the fp32 adjacency from global memory (correct, slow; decided per graph on the device).
 #include "dp_common.h"
+#include <utility>
+#include <vector>
 
 namespace dp {
 
@@ -1626,11 +1628,47 @@ bool l0_geometry(const Level0Fwd& f, L0Geom& g) {
     return false;
 }
 
+// Launch timing for bench.py's roofline object: when switched on (dp_profile_level0), every launch of the two persistent
+// kernels is bracketed by a pair of HIP events on the launch stream.  Eager launches only — a capturing stream is left alone.
+struct L0Prof {
+    std::mutex m;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+};
+L0Prof& l0_prof() {
+    static L0Prof p;
+    return p;
+}
+struct L0Timed {
+    hipStream_t st;
+    int which;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    L0Timed(hipStream_t s, int w) : st(s), which(w) {
+        L0Prof& p = l0_prof();
+        if (!p.on) return;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+            e0 = e1 = nullptr;
+            return;
+        }
+        (void)hipEventRecord(e0, st);
+    }
+    ~L0Timed() {
+        if (!e0) return;
+        (void)hipEventRecord(e1, st);
+        L0Prof& p = l0_prof();
+        std::lock_guard<std::mutex> g(p.m);
+        p.ev[which].emplace_back(e0, e1);
+    }
+};
+
 template <int MI>
 void l0_launch(Seq& q, const L0Args& a, size_t lds_bytes) {
     static DynLdsOnce attr;
     ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_level0_fwd<MI>), 160 * 1024, "k_level0_fwd");
     if (!q.ok()) return;
+    L0Timed timed(q.stream, 0);
     hipLaunchKernelGGL(k_level0_fwd<MI>, dim3(a.f.B * a.T), dim3(L0_NT), lds_bytes, q.stream, a);
     q.check_launch("level0_forward");
 }
@@ -1836,6 +1874,7 @@ void l0b_launch(Seq& q, const L0BArgs& a, size_t lds_bytes) {
     static DynLdsOnce attr;
     ensure_dyn_lds(q, attr, reinterpret_cast<const void*>(&k_level0_bwd<MI>), 160 * 1024, "k_level0_bwd");
     if (!q.ok()) return;
+    L0Timed timed(q.stream, 1);
     hipLaunchKernelGGL(k_level0_bwd<MI>, dim3(a.f.B * a.T), dim3(L0_NT), lds_bytes, q.stream, a);
     q.check_launch("level0_backward");
 }
@@ -1889,6 +1928,38 @@ void level0_backward(Seq& q, const Level0Bwd& f) {
         case 3: l0b_launch<3>(q, a, g.lds_bytes); break;
         default: l0b_launch<4>(q, a, g.lds_bytes); break;
     }
+}
+
+// ---- launch timing of the persistent kernels (include/diffpool_hip.h: dp_profile_level0 / dp_profile_level0_read)
+extern "C" __attribute__((visibility("default"))) int dp_profile_level0(int enable) {
+    L0Prof& p = l0_prof();
+    std::lock_guard<std::mutex> g(p.m);
+    for (auto& v : p.ev) {
+        for (auto& e : v) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        v.clear();
+    }
+    p.on = enable != 0;
+    return DP_OK;
+}
+extern "C" __attribute__((visibility("default"))) int dp_profile_level0_read(int which, double* total_us, int* launches) {
+    if (which < 0 || which > 1 || !total_us || !launches) return DP_ERR_INVALID_ARG;
+    L0Prof& p = l0_prof();
+    std::lock_guard<std::mutex> g(p.m);
+    double tot = 0.0;
+    int n = 0;
+    for (auto& e : p.ev[which]) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.second) != hipSuccess || hipEventElapsedTime(&ms, e.first, e.second) != hipSuccess)
+            return DP_ERR_UNSUPPORTED;
+        tot += (double)ms * 1000.0;
+        ++n;
+    }
+    *total_us = tot;
+    *launches = n;
+    return DP_OK;
 }
 
 #ifdef DP_STAMP

@@ -70,6 +70,14 @@ const char* dp_last_error_string(void);
 int dp_device_error(int clear);
 const char* dp_device_error_describe(int mask);
 
+/* Launch timing of the two persistent level-0 kernels (k_level0_fwd / k_level0_bwd, dp_level0.hip) for bench.py's
+ * roofline object: dp_profile_level0(1) makes every EAGER launch of them (a capturing stream is left alone) record a
+ * pair of HIP events on the launch stream; dp_profile_level0_read(which, &us, &n) waits for the pairs recorded so far
+ * and returns their summed elapsed time in microseconds and their number (which: 0 forward, 1 backward);
+ * dp_profile_level0(0) switches it off and drops the pairs.  No reference counterpart (measurement only). */
+int dp_profile_level0(int enable);
+int dp_profile_level0_read(int which, double* total_us, int* launches);
+
 /* ------------------------------------------------------------------ generic contraction
  * C[b] = act(alpha * op(A[b]) op(B[b]) + beta * C[b] + bias), fp32 MFMA (exact f32).
  * Replaces torch.matmul / @ at encoders.py:965,968,1278,1279,1311.  act: 0 none, 1 relu. */
