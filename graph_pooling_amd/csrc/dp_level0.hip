@@ -14,18 +14,23 @@
 // What crosses workgroups goes through global memory behind barriers of this launch:
 //   * the operand of an aggregation U = A_rows . P needs ALL rows of P of the graph: each workgroup writes the exact
 //     3-plane bf16 split of its rows (the layout dp_agg.hip reads), then a PER-GRAPH barrier (T arrivals);
-//   * apply_bn couples all graphs (statistics per node index over batch x features): row partials (mean, M2), then a
-//     GRID barrier (per-graph counters feeding one global counter);
+//   * apply_bn couples the graphs, but only at equal node index (statistics per node index over batch x features): row
+//     partials (mean, M2), then a COLUMN barrier over the B workgroups that hold the same row block (one counter per row
+//     block; the first build used a grid-wide barrier here — two chained atomics and 220 workgroups' stragglers);
 //   * X' = S^T Z and A' = Tt^T S contract over the node index: per-workgroup partial tiles, a per-graph barrier, then
 //     the graph's workgroups sum disjoint slices in block order (deterministic); the max readout likewise.
-// Barriers are sense-reversing (count + generation, never reset by the host; the last workgroup to FINISH the launch
-// clears every count, so a launch that timed out leaves a clean block too), bounded (a wait that gives up raises
-// DP_DEVERR_BARRIER and a device word the prediction head turns into NaN logits), and need every workgroup resident:
-// the launcher only takes this path when B * T <= CUs with one 512-thread workgroup per CU.
+// Barrier counters only grow inside a launch (the e-th crossing waits for e * arrivals; nothing is reset between
+// crossings and never by the host: the last workgroup to FINISH the launch clears every count, so a launch that timed
+// out leaves a clean block too); waits are bounded (one that gives up raises DP_DEVERR_BARRIER and a device word the
+// prediction head turns into NaN logits) and need every workgroup resident: the launcher only takes this path when
+// B * T <= CUs with one 512-thread workgroup per CU.
 //
 // Memory model (MI355X: per-XCD L2s are not coherent, a CU's L1 is never refreshed by another CU's stores): every byte
-// another workgroup of the launch reads is stored write-through (`sc1`) and loaded `sc1` (raw buffer builtins, aux 16);
-// every storing wave drains vmcnt before the workgroup barrier that precedes its arrival (cdna guide, Guideline 16 R1).
+// another workgroup of the launch reads is stored write-through (`sc1`, raw buffer builtins, aux 16) and every storing
+// wave drains vmcnt before the workgroup barrier that precedes its arrival (cdna guide, Guideline 16 R1).  The regions
+// are WRITE-ONCE per launch — one per aggregation pass / BatchNorm layer / combine, never reused — and no workgroup
+// touches a line of one before the barrier that publishes it, so no L1 or L2 of the launch can hold a stale copy
+// (caches start a launch invalidated) and the consumers read them with plain cached loads.
 //
 // Exactness: as dp_agg.hip — a bf16-exact adjacency (0/1 graphs) is multiplied as bf16 x (hi + mid + lo) planes on the
 // bf16 MFMA with fp32 accumulation, every product exact; a graph whose adjacency is NOT bf16-exact takes an fp32 MFMA
@@ -72,6 +77,8 @@ constexpr int L0_SPIN_LIMIT = 1 << 22;
 // barrier block (ints; every word that is polled or added to sits on a 64-byte line of its own)
 constexpr int BAR_GCOUNT = 0, BAR_DONE = 32, BAR_GFLAG = 48, BAR_ERR = 64, BAR_GRAPH0 = 128;
 constexpr int BAR_GSTRIDE = 48;       // per graph: +0 count, +16 generation, +32 "adjacency not bf16-exact"
+constexpr int BAR_CSTRIDE = 32;       // per row block (after the graphs' entries): the BatchNorm column counter
+constexpr int BAR_MAX_T = 256;        // row blocks per graph <= CUs / B
 
 // ---- write-through / L1-bypassing access to what other workgroups of this launch write or read
 struct ScBuf {
@@ -176,27 +183,58 @@ __device__ inline void l0_mma(const float* A, int lda, const float* B, int ldb, 
 
 // ---- barriers.  Every thread calls; returns false once a wait of this workgroup has given up (sticky).
 // Counters only ever grow inside a launch (the last workgroup to FINISH clears them): the e-th graph barrier of a
-// launch waits for the graph's counter to reach e * T; the e-th grid barrier adds the graph's last arriver to the global
-// counter and waits for e * B there.  `epoch` = {graph arrivals so far / T, grid barriers so far}, kept by the caller.
+// launch waits for the graph's counter to reach e * T, the e-th column barrier for the row block's counter to reach
+// e * B.  `epoch` = crossings so far of each kind, kept by the caller.
 struct L0Epoch {
-    int graph, grid;
+    int graph, grid, col;
 };
-template <bool GRID, typename Args>
+template <typename Args>
 __device__ inline bool l0_barrier(const Args& a, int b, int* sflag /*LDS: [0] ok, [1] failed (sticky)*/, L0Epoch& ep) {
     ep.graph += 1;
-    if (GRID) ep.grid += 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores are acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
         int ok = sflag[1] ? 0 : 1;
         int* gc = a.f.bar + BAR_GRAPH0 + b * BAR_GSTRIDE;
-        int* pollw = GRID ? a.f.bar + BAR_GCOUNT : gc;
-        const int target = (GRID ? ep.grid * a.f.B : ep.graph * a.T) + a.target_bias;
-        const int old = ag_add(gc, 1);
-        if (GRID && old + 1 == ep.graph * a.T) ag_add(a.f.bar + BAR_GCOUNT, 1);   // last of this graph
+        int* pollw = gc;
+        const int target = ep.graph * a.T + a.target_bias;
+        ag_add(gc, 1);
         if (ok) {
             int it = 0;
             while (ag_ld(pollw) < target) {
+                if (++it > a.spin_limit) {
+                    ok = 0;
+                    ag_st(a.f.bar + BAR_ERR, 1);
+                    dev_err_raise(a.dev_err, DP_DEVERR_BARRIER);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        sflag[0] = ok;
+        if (!ok) sflag[1] = 1;
+    }
+    __syncthreads();
+    return sflag[0] != 0;
+}
+
+// BatchNorm's exchange is between the workgroups that hold the SAME row block of the B graphs (statistics are per node
+// index over the batch, encoders.py:1048-1052): a barrier over those B workgroups only — one counter per row block, one
+// atomic per arrival, nobody waits for another row block's straggler.  It says nothing about the other row blocks of
+// the caller's graph (the graph barriers do).  Same monotonic-counter scheme: the e-th crossing waits for e * B.
+template <typename Args>
+__device__ inline bool l0_col_barrier(const Args& a, int rb, int* sflag, L0Epoch& ep) {
+    ep.col += 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = sflag[1] ? 0 : 1;
+        int* cc = a.f.bar + BAR_GRAPH0 + a.f.B * BAR_GSTRIDE + rb * BAR_CSTRIDE;
+        const int target = ep.col * a.f.B + a.target_bias;
+        ag_add(cc, 1);
+        if (ok) {
+            int it = 0;
+            while (ag_ld(cc) < target) {
                 if (++it > a.spin_limit) {
                     ok = 0;
                     ag_st(a.f.bar + BAR_ERR, 1);
@@ -482,7 +520,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
     float* BIAS = lds + a.lds_scr + a.scr_floats;          // every layer's biases [l][g][64], then assign_pred's [64]
     int* sflag = reinterpret_cast<int*>(BIAS + (2 * DP_MAX_LAYERS + 1) * 64);   // [0] ok, [1] failed, [2] block flag, [3] last
     if (tid < 4) sflag[tid] = 0;
-    L0Epoch ep{0, 0};
+    L0Epoch ep{0, 0, 0};
 
     // Exchange buffers are WRITE-ONCE per launch (one region per pass): a reader can only ever fetch a line after its
     // writers are done, so no cache of this launch can hold a stale copy and the reads are ordinary cached loads (the
@@ -602,7 +640,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         l0_write_split(vs_wr(0, CTt), PT, ct, CTt, a.K8, k8_0, nk8, nrows);
     }
     L0_STAMP(6);
-    bool ok = l0_barrier<false>(a, b, sflag, ep);
+    bool ok = l0_barrier(a, b, sflag, ep);
     L0_STAMP(7);
     const bool exact = ag_ld(f.bar + BAR_GRAPH0 + b * BAR_GSTRIDE + 32) == 0;
     const float* Arows = f.A + ((long)b * N + r0) * N;             // fp32 fallback operands
@@ -698,7 +736,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         L0_STAMP(10 + 8 * l);
         if (last) break;
         // ---- apply_bn: every graph's partials of my node indices (grid barrier), then x = (relu(y) - mu) * rstd
-        if (f.bn) ok = l0_barrier<true>(a, b, sflag, ep) && ok;
+        if (f.bn) ok = l0_col_barrier(a, rb, sflag, ep) && ok;
         else lds_barrier();
         L0_STAMP(11 + 8 * l);
         const int ctn = f.st[0].dims[l + 2] + (G == 2 ? f.st[1].dims[l + 2] : 0);
@@ -778,7 +816,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
             l0_write_split(vs_wr(l + 1, CTn), PTn, ctn, CTn, a.K8, k8_0, nk8, nrows);
         }
         L0_STAMP(14 + 8 * l);
-        ok = l0_barrier<false>(a, b, sflag, ep) && ok;
+        ok = l0_barrier(a, b, sflag, ep) && ok;
         L0_STAMP(15 + 8 * l);
         ct = ctn;
     }
@@ -845,7 +883,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
             const unsigned short* atp = f.pkAt + ((long)b * N + r0) * f.pk_ld;
             L0RowStage<MI> atq;
             l0_stage_issue<MI>(atq, atp, f.pk_ld, nrows, 0);
-            ok = l0_barrier<false>(a, b, sflag, ep) && ok;
+            ok = l0_barrier(a, b, sflag, ep) && ok;
             L0_STAMP(44);
             l0_stage_commit<MI>(atq, Alds, a.ldp, f.pk_ld, nrows, 0);
             for (int seg = 1; seg < segs; ++seg) {
@@ -931,7 +969,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         }
     }
     L0_STAMP(50);
-    if ((G == 2 && K > 0) || f.do_max) ok = l0_barrier<false>(a, b, sflag, ep) && ok;
+    if ((G == 2 && K > 0) || f.do_max) ok = l0_barrier(a, b, sflag, ep) && ok;
     L0_STAMP(51);
     // ------------------------------------------------------------------ combine (block order: deterministic)
     if (G == 2 && K > 0) {
@@ -1006,6 +1044,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
             ag_st(f.bar + BAR_GRAPH0 + g * BAR_GSTRIDE, 0);
             ag_st(f.bar + BAR_GRAPH0 + g * BAR_GSTRIDE + 32, 0);
         }
+        for (int t = tid; t < a.T; t += L0_NT) ag_st(f.bar + BAR_GRAPH0 + f.B * BAR_GSTRIDE + t * BAR_CSTRIDE, 0);
         if (tid == 0) {
             ag_st(f.bar + BAR_GCOUNT, 0);
             ag_st(f.bar + BAR_GFLAG, 0);
@@ -1127,7 +1166,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
     float* EXT = SCR + a.slots_floats;
     int* sflag = reinterpret_cast<int*>(SCR + a.scr_floats);
     if (tid < 4) sflag[tid] = 0;
-    L0Epoch ep{0, 0};
+    L0Epoch ep{0, 0, 0};
     const bool exact = f.pk_flag[0] == 0;
     const int D = f.ldz[0], Da = f.ldz[1], K = f.K;
     const float* Arows = f.A + ((long)b * N + r0) * N;
@@ -1177,7 +1216,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
             // my rows of the packed A: asked for in front of the barrier, written over the staged rows behind it
             L0RowStage<MI> q;
             l0_stage_issue<MI>(q, f.pkA + ((long)b * N + r0) * f.pk_ld, f.pk_ld, nrows, 0);
-            ok = l0_barrier<false>(a, b, sflag, ep) && ok;
+            ok = l0_barrier(a, b, sflag, ep) && ok;
             l0_stage_commit<MI>(q, Alds, a.ldp, f.pk_ld, nrows, 0);
             const int segs = (a.steps * 32 + 511) / 512;
             for (int seg = 1; seg < segs; ++seg) {
@@ -1299,6 +1338,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                 }
             }
         }
+        L0B_STAMP(44 + 2 * (L - 1 - l));
         // ---- BatchNorm / ReLU / l2-normalise backward of my rows -> dU (each team reads back only its own means)
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -1337,6 +1377,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                 }
             }
             dot = row16_sum(dot);
+            if (j == 0) L0B_STAMP(45 + 2 * (L - 1 - l));
 #pragma unroll
             for (int k = 0; k < L0_NK; ++k) {
                 const int c = tl + 16 * k;
@@ -1419,7 +1460,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
         if (!have_at) {
             L0RowStage<MI> q;
             l0_stage_issue<MI>(q, f.pkAt + ((long)b * N + r0) * f.pk_ld, f.pk_ld, nrows, 0);
-            ok = l0_barrier<false>(a, b, sflag, ep) && ok;
+            ok = l0_barrier(a, b, sflag, ep) && ok;
             l0_stage_commit<MI>(q, Alds, a.ldp, f.pk_ld, nrows, 0);
             const int segs = (a.steps * 32 + 511) / 512;
             for (int seg = 1; seg < segs; ++seg) {
@@ -1429,7 +1470,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
             have_at = true;
             lds_barrier();
         } else {
-            ok = l0_barrier<false>(a, b, sflag, ep) && ok;
+            ok = l0_barrier(a, b, sflag, ep) && ok;
         }
         L0B_STAMP(10 + 8 * (L - 1 - l));
         // ---- G = A^T dU (my rows), summed in place into the first reduce slot
@@ -1496,14 +1537,14 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                 }
             }
             L0B_STAMP(14 + 8 * (L - 1 - l));
-            ok = l0_barrier<true>(a, b, sflag, ep) && ok;
+            ok = l0_col_barrier(a, rb, sflag, ep) && ok;
         } else {
             lds_barrier();
         }
         L0B_STAMP(15 + 8 * (L - 1 - l));
     }
     // ------------------------------------------------------------------ the graph's parameter gradients: one slab row
-    ok = l0_barrier<false>(a, b, sflag, ep) && ok;
+    ok = l0_barrier(a, b, sflag, ep) && ok;
     L0B_STAMP(40);
     {
         const int n4 = a.P0 / 4;
@@ -1543,6 +1584,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
     lds_barrier();
     if (sflag[3]) {
         for (int g = tid; g < f.B; g += L0_NT) ag_st(f.bar + BAR_GRAPH0 + g * BAR_GSTRIDE, 0);
+        for (int t = tid; t < a.T; t += L0_NT) ag_st(f.bar + BAR_GRAPH0 + f.B * BAR_GSTRIDE + t * BAR_CSTRIDE, 0);
         if (tid == 0) {
             ag_st(f.bar + BAR_GCOUNT, 0);
             ag_st(f.bar + BAR_DONE, 0);
@@ -1675,7 +1717,7 @@ void l0_launch(Seq& q, const L0Args& a, size_t lds_bytes) {
 
 }  // namespace
 
-size_t level0_bar_ints(int B) { return (size_t)BAR_GRAPH0 + (size_t)BAR_GSTRIDE * B; }
+size_t level0_bar_ints(int B) { return (size_t)BAR_GRAPH0 + (size_t)BAR_GSTRIDE * B + (size_t)BAR_CSTRIDE * BAR_MAX_T; }
 // write-once exchange regions: one split operand per aggregation pass, one partial block per BatchNorm layer
 static void l0_vs_layout(const Level0Fwd& f, long (&off)[DP_MAX_LAYERS + 1], size_t& total) {
     const int K8 = ((f.N + 31) / 32) * 4;

@@ -24,6 +24,9 @@ for i in range(3):
                   o + 4: f"layer {2 - i}: reduce to G + sync", o + 5: f"layer {2 - i}: dW, dx_in + sync",
                   o + 6: f"layer {2 - i}: dW stored, BN partials", o + 7: f"layer {2 - i}: GRID barrier / sync"})
 names.update({40: "graph barrier (gradients)", 41: "combine + sync"})
+sub = {}
+for i in range(3):
+    sub[8 + 8 * i] = [(44 + 2 * i, "BN partials combined"), (45 + 2 * i, "first item's loads landed, dot done")]
 for wgi, label in enumerate(("first", "middle", "last")):
     t = [buf[wgi * 64 + i] for i in range(64)]
     print(f"--- {label} workgroup: total {t[41] - t[0]} cycles")
@@ -31,5 +34,8 @@ for wgi, label in enumerate(("first", "middle", "last")):
     for i in sorted(names):
         if t[i] == 0:
             continue
+        for si, sn in sub.get(i, []):
+            if t[si]:
+                print(f"      . {sn:38s} {t[si] - prev:7d} (since phase start)")
         print(f"  {names[i]:44s} {t[i] - prev:7d}")
         prev = t[i]
