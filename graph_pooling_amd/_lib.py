@@ -117,9 +117,16 @@ _PROTOS = {
     "dp_encoder_save_locate": (_I, [C.POINTER(EncoderCfg), _I, _I, C.POINTER(_Z), C.POINTER(_Z)]),
     "dp_encoder_forward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
     "dp_encoder_backward": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
+    "dp_encoder_forward_packed": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I,
+                                       _P]),
+    "dp_encoder_backward_packed": (_I, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I,
+                                        _P]),
     "dp_build_batch": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dp_build_batch_packed": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dp_clip_adam_workspace_bytes": (_Z, []),
     "dp_clip_adam_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P, _P, _Z, _P]),
+    "dp_clip_adam_step_counted": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P, _P, _Z, _P]),
+    "dp_gather_labels": (_I, [_P, _P, _I, _P]),
     "dp_loss_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "dp_loss_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "dp_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),

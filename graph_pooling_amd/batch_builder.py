@@ -116,11 +116,13 @@ class DeviceBatchBuilder:
         self._stage[slot] = (buf, ev)
         return packed
 
-    def build(self, indices: Sequence[int], check: bool = True) -> Dict[str, object]:
+    def build(self, indices: Sequence[int], check: bool = True, packed: bool = False) -> Dict[str, object]:
         """Device tensors `adj`, `feats` (= `assign_feats`), `label`, plus `num_nodes` as the host int array the
         reference passes (train.py:200) and `num_nodes_device`.  The batch is validated on the host (sizes, label
-        range) before anything is shipped; `check` additionally reads back the kernel's skipped-entry counter."""
-        lib = _lib.load()
+        range) before anything is shipped; `check` additionally reads back the kernel's skipped-entry counter.
+        packed=True: `adj` is a `PackedAdjacency` (bf16 rows the kernels multiply from, written directly by
+        dp_build_batch_packed; the edge lists are undirected, so A and A^T share one buffer) — no fp32 [B,N,N] batch is
+        written; the encoders' forward takes it in place of the dense tensor."""
         src, dst, edge_ptr, lab, node_ptr, glabel, max_edges = self.ds.gather(indices)
         B = len(glabel)
         if B == 0:
@@ -134,22 +136,43 @@ class DeviceBatchBuilder:
         dev = self.device
         parts = [src, dst, edge_ptr, lab, node_ptr]
         offs = np.cumsum([0] + [len(p) for p in parts])
-        packed = self._to_device(parts)
-        view = [packed[offs[i]:offs[i + 1]] for i in range(len(parts))]
-        adj = torch.empty(B, self.N, self.N, device=dev, dtype=torch.float32)
+        shipped = self._to_device(parts)
+        base = shipped.data_ptr()
+        # (an empty array's pointer is never dereferenced)
+        out = self.emit([base + 4 * int(offs[i]) for i in range(len(parts))], B, max_edges, packed)
+        out["_shipped"] = shipped                      # keeps the device copy of the edge lists alive with the batch
+        if check and int(out["errors"].item()) != 0:
+            raise RuntimeError(f"dp_build_batch skipped {int(out['errors'].item())} out-of-range entries")
+        out["label"] = torch.from_numpy(np.ascontiguousarray(glabel)).to(dev)
+        out["num_nodes"] = n.astype(np.int32)
+        return out
+
+    def emit(self, ptrs, B: int, max_edges: int, packed: bool) -> Dict[str, object]:
+        """The device side of `build`: allocate the batch and enqueue dp_build_batch (or _packed) on the current stream.
+        ptrs = addresses of (src, dst, edge_ptr[B+1], node_label, node_ptr[B+1]) as int32 arrays the DEVICE can read —
+        device memory, or pinned host memory (the kernels then fetch the lists over PCIe themselves, which is what a
+        captured training step does: train_step.CapturedTrainStep)."""
+        from .encoders import PackedAdjacency
+        lib = _lib.load()
+        dev = self.device
         feats = torch.empty(B, self.N, self.Fout, device=dev, dtype=torch.float32)
         assign = torch.empty(B, self.N, self.N + self.Fout, device=dev, dtype=torch.float32) if self.assign_id else None
         degree = torch.empty(B * self.N, device=dev, dtype=torch.int32) if self.mode >= 2 else None
         nn_dev = torch.empty(B, device=dev, dtype=torch.int32)
         errors = torch.empty(1, device=dev, dtype=torch.int32)
-        _lib.require_gpu_tensor(adj, "adj")
-        ptr = lambda t: t.data_ptr() if t.numel() else errors.data_ptr()          # noqa: E731  (never dereferenced)
-        _lib.check(lib.dp_build_batch(ptr(view[0]), ptr(view[1]), view[2].data_ptr(), ptr(view[3]), view[4].data_ptr(),
-                                      adj.data_ptr(), feats.data_ptr(), _lib.ptr(assign), nn_dev.data_ptr(),
-                                      errors.data_ptr(), _lib.ptr(degree), B, self.N, self.F, self.mode, 1, max_edges,
-                                      _lib.current_stream()), "dp_build_batch")
-        if check and int(errors.item()) != 0:
-            raise RuntimeError(f"dp_build_batch skipped {int(errors.item())} out-of-range entries")
-        label = torch.from_numpy(np.ascontiguousarray(glabel)).to(dev)
-        return {"adj": adj, "feats": feats, "assign_feats": assign if assign is not None else feats, "label": label,
-                "num_nodes": n.astype(np.int32), "num_nodes_device": nn_dev}
+        _lib.require_gpu_tensor(feats, "batch")
+        if packed:
+            pk = torch.empty(B, self.N, lib.dp_adj_pack_ld(self.N), device=dev, dtype=torch.int16)
+            _lib.check(lib.dp_build_batch_packed(ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], pk.data_ptr(),
+                                                 pk.data_ptr(), feats.data_ptr(), _lib.ptr(assign), nn_dev.data_ptr(),
+                                                 errors.data_ptr(), _lib.ptr(degree), B, self.N, self.F, self.mode, 1,
+                                                 max_edges, _lib.current_stream()), "dp_build_batch_packed")
+            adj = PackedAdjacency(pk, pk, self.N)
+        else:
+            adj = torch.empty(B, self.N, self.N, device=dev, dtype=torch.float32)
+            _lib.check(lib.dp_build_batch(ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], adj.data_ptr(), feats.data_ptr(),
+                                          _lib.ptr(assign), nn_dev.data_ptr(), errors.data_ptr(), _lib.ptr(degree), B,
+                                          self.N, self.F, self.mode, 1, max_edges, _lib.current_stream()),
+                       "dp_build_batch")
+        return {"adj": adj, "feats": feats, "assign_feats": assign if assign is not None else feats,
+                "num_nodes_device": nn_dev, "errors": errors}

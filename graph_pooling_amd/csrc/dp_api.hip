@@ -123,10 +123,11 @@ void ensure_dyn_lds(Seq& q, DynLdsOnce& st, const void* fn, int bytes, const cha
 // dp_model.hip
 int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                     const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
-                    float* assign_out, void* save, int mode, long long* labels_out);
+                    float* assign_out, void* save, int mode, long long* labels_out, const PackedAdj* given = nullptr);
 int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                      const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
-                     const float* d_assign, float* grads, const void* save, int prezeroed);
+                     const float* d_assign, float* grads, const void* save, int prezeroed,
+                     const PackedAdj* given = nullptr);
 size_t encoder_save_bytes(const dp_encoder_cfg& c);
 int encoder_validate(const dp_encoder_cfg* c);
 int encoder_save_locate(const dp_encoder_cfg& c, int level, int field, size_t* offset, size_t* count);
@@ -726,6 +727,44 @@ int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const fl
                             prezeroed);
 }
 
+int dp_encoder_forward_packed(const dp_encoder_cfg* cfg, const float* params, const float* x, const void* adj_pk,
+                              const void* adj_pkt,
+                       const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
+                       float* assign_out, long long* labels_out, void* save, size_t save_bytes, void* workspace,
+                       size_t workspace_bytes, int mode, void* stream) {
+    int rc = encoder_validate(cfg);
+    if (rc != DP_OK) return rc;
+    NOTNULL(params); NOTNULL(x); NOTNULL(adj_pk); NOTNULL(adj_pkt); NOTNULL(ypred); NOTNULL(save);
+    DP_CHECK_ARG(cfg->num_pooling == 0 || assign_x, "assign_x is NULL");
+    DP_CHECK_ARG(save_bytes >= encoder_save_bytes(*cfg), "save buffer too small: %zu < %zu", save_bytes,
+                 encoder_save_bytes(*cfg));
+    DEVICE_GATE("dp_encoder_forward_packed");
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    DP_CHECK_ARG((mode & ~(DP_MODE_TRAIN)) == 0, "mode=%d: DP_MODE_EVAL or DP_MODE_TRAIN", mode);
+    const PackedAdj given{static_cast<const unsigned short*>(adj_pk), static_cast<const unsigned short*>(adj_pkt),
+                          adj_pack_ld(cfg->N), nullptr};
+    return encoder_forward(q, *cfg, params, x, nullptr, assign_x, num_nodes, dropout, ypred, assign_out, save, mode,
+                           labels_out, &given);
+}
+
+int dp_encoder_backward_packed(const dp_encoder_cfg* cfg, const float* params, const float* x, const void* adj_pk,
+                               const void* adj_pkt,
+                        const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
+                        const float* d_assign, float* grads, const void* save, size_t save_bytes, void* workspace,
+                        size_t workspace_bytes, int prezeroed, void* stream) {
+    int rc = encoder_validate(cfg);
+    if (rc != DP_OK) return rc;
+    NOTNULL(params); NOTNULL(x); NOTNULL(adj_pk); NOTNULL(adj_pkt); NOTNULL(d_ypred); NOTNULL(grads); NOTNULL(save);
+    DP_CHECK_ARG(save_bytes >= encoder_save_bytes(*cfg), "save buffer too small: %zu < %zu", save_bytes,
+                 encoder_save_bytes(*cfg));
+    DEVICE_GATE("dp_encoder_backward_packed");
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    const PackedAdj given{static_cast<const unsigned short*>(adj_pk), static_cast<const unsigned short*>(adj_pkt),
+                          adj_pack_ld(cfg->N), nullptr};
+    return encoder_backward(q, *cfg, params, x, nullptr, assign_x, num_nodes, dropout, d_ypred, d_assign, grads, save,
+                            prezeroed, &given);
+}
+
 size_t dp_loss_workspace_bytes(int B, int N, int K, int linkpred) {
     size_t f = sized([&](Seq& q) { loss_fwd_seq(q, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, 1, N, K, linkpred); });
     size_t b = sized([&](Seq& q) { loss_bwd_seq(q, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, 1, N, K, linkpred); });
@@ -768,12 +807,54 @@ int dp_build_batch(const int* edge_src, const int* edge_dst, const int* edge_ptr
                  "label-based features need node labels and F > 0");
     DP_CHECK_ARG(feature_mode < 2 || degree, "deg / deg-num features need the degree workspace (B*N ints)");
     Seq q(STREAM(stream), nullptr, 0);
-    build_batch(q, edge_src, edge_dst, edge_ptr, node_label, node_ptr, adj, feats, assign_feats, num_nodes, errors,
-                degree, B, N, F, feature_mode, symmetric, max_edges_per_graph);
+    build_batch(q, edge_src, edge_dst, edge_ptr, node_label, node_ptr, adj, nullptr, nullptr, feats, assign_feats,
+                num_nodes, errors, degree, B, N, F, feature_mode, symmetric, max_edges_per_graph);
+    return q.err;
+}
+
+int dp_build_batch_packed(const int* edge_src, const int* edge_dst, const int* edge_ptr, const int* node_label,
+                          const int* node_ptr, void* adj_pk, void* adj_pkt, float* feats, float* assign_feats,
+                          int* num_nodes, int* errors, int* degree, int B, int N, int F, int feature_mode, int symmetric,
+                          int max_edges_per_graph, void* stream) {
+    NOTNULL(edge_src); NOTNULL(edge_dst); NOTNULL(edge_ptr); NOTNULL(node_ptr); NOTNULL(adj_pk); NOTNULL(adj_pkt);
+    NOTNULL(num_nodes); NOTNULL(errors);
+    NONNEG(B); NONNEG(N);
+    DP_CHECK_ARG(feature_mode >= 0 && feature_mode <= 3, "feature_mode=%d (0 default, 1 id, 2 deg-num, 3 deg)",
+                 feature_mode);
+    DP_CHECK_ARG(adj_pk != adj_pkt || symmetric, "A and A^T may share one buffer only for a symmetric edge list");
+    const bool labels = feature_mode == 0 || feature_mode == 3;
+    DP_CHECK_ARG(!(feats || assign_feats) || !labels || (node_label && F > 0),
+                 "label-based features need node labels and F > 0");
+    DP_CHECK_ARG(feature_mode < 2 || degree, "deg / deg-num features need the degree workspace (B*N ints)");
+    Seq q(STREAM(stream), nullptr, 0);
+    build_batch(q, edge_src, edge_dst, edge_ptr, node_label, node_ptr, nullptr, static_cast<unsigned short*>(adj_pk),
+                static_cast<unsigned short*>(adj_pkt), feats, assign_feats, num_nodes, errors, degree, B, N, F,
+                feature_mode, symmetric, max_edges_per_graph);
+    return q.err;
+}
+
+int dp_gather_labels(const long long* graph_label, long long* label_out, int B, void* stream) {
+    NOTNULL(graph_label); NOTNULL(label_out);
+    NONNEG(B);
+    Seq q(STREAM(stream), nullptr, 0);
+    gather_labels(q, graph_label, label_out, B);
     return q.err;
 }
 
 size_t dp_clip_adam_workspace_bytes(void) { return 4096; }
+int dp_clip_adam_step_counted(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, int* step_counter,
+                              float lr, float beta1, float beta2, float eps, float max_norm, float* total_norm_out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    NOTNULL(params); NOTNULL(grads); NOTNULL(exp_avg); NOTNULL(exp_avg_sq); NOTNULL(step_counter);
+    DP_CHECK_ARG(n >= 0, "n=%ld must be >= 0", n);
+    DP_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "betas (%g, %g) must lie in [0, 1)",
+                 (double)beta1, (double)beta2);
+    DEVICE_GATE("dp_clip_adam_step_counted");
+    Seq q(STREAM(stream), workspace, workspace_bytes);
+    clip_adam_step(q, params, grads, exp_avg, exp_avg_sq, n, max_norm, beta1, beta2, eps, 0.f, 0.f, total_norm_out,
+                   step_counter, lr);
+    return q.err;
+}
 int dp_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, int step, float lr,
                       float beta1, float beta2, float eps, float max_norm, float* total_norm_out, void* workspace,
                       size_t workspace_bytes, void* stream) {

@@ -33,6 +33,40 @@ __global__ __launch_bounds__(256) void k_scatter_edges(const int* src, const int
     if (bad) atomicAdd(errors, bad);
 }
 
+// The same scatter into the PACKED adjacency the encoders multiply from (dp_adj_pack's layout: bf16 rows of ld = N
+// rounded up to 8 elements): 1.0 = 0x3F80.  P holds A, Pt holds A^T; for an undirected edge list (symmetric != 0) A is
+// its own transpose and the caller may pass Pt == P (one 2-byte store pair per edge instead of two).
+__global__ __launch_bounds__(256) void k_scatter_edges_packed(const int* src, const int* dst, const int* edge_ptr,
+                                                              const int* node_ptr, unsigned short* P, unsigned short* Pt,
+                                                              int B, int N, int ld, int symmetric, int* errors,
+                                                              int* degree) {
+    const int b = blockIdx.y;
+    const int e0 = edge_ptr[b], e1 = edge_ptr[b + 1];
+    const int nb = min(node_ptr[b + 1] - node_ptr[b], N);
+    unsigned short* A = P + (long)b * N * ld;
+    unsigned short* At = Pt + (long)b * N * ld;
+    const unsigned short one = 0x3F80;
+    int bad = 0;
+    for (int e = e0 + blockIdx.x * 256 + threadIdx.x; e < e1; e += gridDim.x * 256) {
+        const int s = src[e], d = dst[e];
+        if (s < 0 || d < 0 || s >= nb || d >= nb) {
+            ++bad;
+            continue;
+        }
+        A[(long)s * ld + d] = one;
+        if (symmetric) A[(long)d * ld + s] = one;
+        if (At != A) {
+            At[(long)d * ld + s] = one;
+            if (symmetric) At[(long)s * ld + d] = one;
+        }
+        if (degree) {
+            atomicAdd(degree + (long)b * N + s, 1);
+            if (symmetric) atomicAdd(degree + (long)b * N + d, 1);
+        }
+    }
+    if (bad) atomicAdd(errors, bad);
+}
+
 // Node features in the sampler's modes (graph_sampler.py:33-59, 85-87); feats / assign are zero-filled beforehand.
 //   0 default: one-hot node label            1 id: identity of size N (padded rows too)
 //   2 deg-num: the degree, one column        3 deg: one-hot degree capped at 10, then the one-hot node label
@@ -80,12 +114,18 @@ __global__ __launch_bounds__(256) void k_node_features(const int* label, const i
     }
 }
 
+// adj (fp32 dense) or pk / pkt (packed bf16, ld = adj_pack_ld(N)): exactly one of the two forms is written
 void build_batch(Seq& q, const int* src, const int* dst, const int* edge_ptr, const int* label, const int* node_ptr,
-                 float* adj, float* feats, float* assign, int* num_nodes, int* errors, int* degree, int B, int N, int F,
-                 int mode, int symmetric, int max_edges_per_graph) {
+                 float* adj, unsigned short* pk, unsigned short* pkt, float* feats, float* assign, int* num_nodes,
+                 int* errors, int* degree, int B, int N, int F, int mode, int symmetric, int max_edges_per_graph) {
     if (!q.ok() || B <= 0) return;
     const int Fout = mode == 0 ? F : (mode == 1 ? N : (mode == 2 ? 1 : 11 + F));
-    zero_fill(q, adj, (size_t)B * N * N * sizeof(float));
+    const int ld = adj_pack_ld(N);
+    if (adj) zero_fill(q, adj, (size_t)B * N * N * sizeof(float));
+    else {
+        zero_fill(q, pk, (size_t)B * N * ld * sizeof(unsigned short));
+        if (pkt != pk) zero_fill(q, pkt, (size_t)B * N * ld * sizeof(unsigned short));
+    }
     if (feats) zero_fill(q, feats, (size_t)B * N * Fout * sizeof(float));
     if (assign) zero_fill(q, assign, (size_t)B * N * (N + Fout) * sizeof(float));
     const bool need_deg = mode == 2 || mode == 3;
@@ -93,13 +133,26 @@ void build_batch(Seq& q, const int* src, const int* dst, const int* edge_ptr, co
     zero_small(q, errors, sizeof(int));
     int gx = (max_edges_per_graph + 255) / 256;
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
-    hipLaunchKernelGGL(k_scatter_edges, dim3(gx, B), dim3(256), 0, q.stream, src, dst, edge_ptr, node_ptr, adj, B, N,
-                       symmetric, errors, need_deg ? degree : (int*)nullptr);
+    if (adj)
+        hipLaunchKernelGGL(k_scatter_edges, dim3(gx, B), dim3(256), 0, q.stream, src, dst, edge_ptr, node_ptr, adj, B, N,
+                           symmetric, errors, need_deg ? degree : (int*)nullptr);
+    else
+        hipLaunchKernelGGL(k_scatter_edges_packed, dim3(gx, B), dim3(256), 0, q.stream, src, dst, edge_ptr, node_ptr, pk,
+                           pkt, B, N, ld, symmetric, errors, need_deg ? degree : (int*)nullptr);
     q.check_launch("scatter_edges");
     int gn = (N + 255) / 256;
     hipLaunchKernelGGL(k_node_features, dim3(gn, B), dim3(256), 0, q.stream, label, node_ptr, degree, feats, assign,
                        num_nodes, B, N, F, Fout, mode, errors);
     q.check_launch("node_features");
+}
+
+__global__ __launch_bounds__(256) void k_gather_labels(const long long* src, long long* dst, int B) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B; i += gridDim.x * 256) dst[i] = src[i];
+}
+void gather_labels(Seq& q, const long long* src, long long* dst, int B) {
+    if (!q.ok() || B <= 0) return;
+    hipLaunchKernelGGL(k_gather_labels, dim3((B + 255) / 256), dim3(256), 0, q.stream, src, dst, B);
+    q.check_launch("gather_labels");
 }
 
 }  // namespace dp

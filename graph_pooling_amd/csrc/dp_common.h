@@ -537,12 +537,15 @@ void head_bwd(Seq& q, const HeadBwdArgs& a);
 
 // (dp_batch.hip)
 void build_batch(Seq& q, const int* src, const int* dst, const int* edge_ptr, const int* label, const int* node_ptr,
-                 float* adj, float* feats, float* assign, int* num_nodes, int* errors, int* degree, int B, int N, int F,
-                 int mode, int symmetric, int max_edges_per_graph);
+                 float* adj, unsigned short* pk, unsigned short* pkt, float* feats, float* assign, int* num_nodes,
+                 int* errors, int* degree, int B, int N, int F, int mode, int symmetric, int max_edges_per_graph);
+
+void gather_labels(Seq& q, const long long* src, long long* dst, int B);
 
 // (dp_optim.hip)
 void clip_adam_step(Seq& q, float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_norm,
-                    float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt, float* total_norm_out);
+                    float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt, float* total_norm_out,
+                    int* step_counter = nullptr, float lr = 0.f);
 
 // (dp_meanagg.hip) CSR neighbour aggregation: out[i] = (mean | sum) of table[indices[indptr[i]:indptr[i+1]]] (+ beta out)
 void csr_aggregate_fwd(Seq& q, const float* table, int ldt, const int* indptr, const int* indices, float* out, int ldo,

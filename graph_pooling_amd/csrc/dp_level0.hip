@@ -486,7 +486,7 @@ __device__ __forceinline__ void l0_stage_commit(const L0RowStage<MI>& s, unsigne
         const int row = tr + 8 * u;
         const bool in = row < nrows && c8 * 8 < ld;
         const u32x4 v = in ? s.q[u] : (u32x4){0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(Alds + row * ldp + c8 * 8) = v;
+        if (c8 * 8 + 8 <= ldp) *reinterpret_cast<u32x4*>(Alds + row * ldp + c8 * 8) = v;
     }
 }
 
@@ -546,7 +546,27 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
     float* const W0s0 = X0s1 + RB * din0_1;
     float* const W0s1 = W0s0 + ((din0_0 * f.st[0].dims[1] + 3) & ~3);
     float* const PT = W0s1 + (G == 2 ? ((din0_1 * f.st[1].dims[1] + 3) & ~3) : 0);
-    {
+    const auto side_loads = [&]() {
+        l0_copy_in<4>(X0s0, f.x0[0] + ((long)b * N + r0) * din0_0, nrows * din0_0, RB * din0_0);
+        l0_copy_in<4>(W0s0, f.params + f.st[0].w_off[0], din0_0 * f.st[0].dims[1]);
+        if (G == 2) {
+            l0_copy_in<4>(X0s1, f.x0[1] + ((long)b * N + r0) * din0_1, nrows * din0_1, RB * din0_1);
+            l0_copy_in<4>(W0s1, f.params + f.st[1].w_off[0], din0_1 * f.st[1].dims[1]);
+        }
+        // biases: one 64-float slot per (layer, stack), zeros where a layer has none
+        for (int e = tid; e < (2 * L + 1) * 64; e += L0_NT) {
+            const int slot = e >> 6, c = e & 63;
+            float v0 = 0.f;
+            if (slot < 2 * L) {
+                const int l = slot >> 1, g = slot & 1;
+                if (g < G && f.st[g].b_off[l] >= 0 && c < f.st[g].dims[l + 1]) v0 = f.params[f.st[g].b_off[l] + c];
+            } else if (G == 2 && f.bp_off >= 0 && c < f.K) {
+                v0 = f.params[f.bp_off + c];
+            }
+            BIAS[(slot < 2 * L ? slot : 2 * DP_MAX_LAYERS) * 64 + c] = v0;
+        }
+    };
+    if (f.A) {
         const float* Ab = f.A + ((long)b * N + r0) * N;
         unsigned short* Pb = f.pkA + ((long)b * N + r0) * f.pk_ld;
         const int tq = tid & 127, tr = tid >> 7;           // 128 column quads x 4 row lanes
@@ -557,26 +577,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
 #pragma unroll
             for (int u = 0; u < 4 * MI; ++u)
                 v[u] = *reinterpret_cast<const f32x4_u*>(Ab + (long)min(tr + 4 * u, nrows - 1) * N + min(c, N - 4));
-            if (seg == 0) {
-                l0_copy_in<4>(X0s0, f.x0[0] + ((long)b * N + r0) * din0_0, nrows * din0_0, RB * din0_0);
-                l0_copy_in<4>(W0s0, f.params + f.st[0].w_off[0], din0_0 * f.st[0].dims[1]);
-                if (G == 2) {
-                    l0_copy_in<4>(X0s1, f.x0[1] + ((long)b * N + r0) * din0_1, nrows * din0_1, RB * din0_1);
-                    l0_copy_in<4>(W0s1, f.params + f.st[1].w_off[0], din0_1 * f.st[1].dims[1]);
-                }
-                // biases: one 64-float slot per (layer, stack), zeros where a layer has none
-                for (int e = tid; e < (2 * L + 1) * 64; e += L0_NT) {
-                    const int slot = e >> 6, c = e & 63;
-                    float v0 = 0.f;
-                    if (slot < 2 * L) {
-                        const int l = slot >> 1, g = slot & 1;
-                        if (g < G && f.st[g].b_off[l] >= 0 && c < f.st[g].dims[l + 1]) v0 = f.params[f.st[g].b_off[l] + c];
-                    } else if (G == 2 && f.bp_off >= 0 && c < f.K) {
-                        v0 = f.params[f.bp_off + c];
-                    }
-                    BIAS[(slot < 2 * L ? slot : 2 * DP_MAX_LAYERS) * 64 + c] = v0;
-                }
-            }
+            if (seg == 0) side_loads();
 #pragma unroll
             for (int u = 0; u < 4 * MI; ++u) {
                 const int row = tr + 4 * u;
@@ -591,6 +592,18 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
                 if (c < a.ldp) *reinterpret_cast<u16x4*>(Alds + row * a.ldp + c) = h;
                 if (row < nrows && c < f.pk_ld) *reinterpret_cast<u16x4*>(Pb + (long)row * f.pk_ld + c) = h;
             }
+        }
+    } else {
+        // the adjacency arrives packed (dp_encoder_forward_packed): my bf16 rows go to LDS as they are
+        L0RowStage<MI> q;
+        const unsigned short* rows = f.pkA + ((long)b * N + r0) * f.pk_ld;
+        l0_stage_issue<MI>(q, rows, f.pk_ld, nrows, 0);
+        side_loads();
+        l0_stage_commit<MI>(q, Alds, a.ldp, f.pk_ld, nrows, 0);
+        const int segs = (a.steps * 32 + 511) / 512;
+        for (int seg = 1; seg < segs; ++seg) {
+            l0_stage_issue<MI>(q, rows, f.pk_ld, nrows, seg);
+            l0_stage_commit<MI>(q, Alds, a.ldp, f.pk_ld, nrows, seg);
         }
     }
     L0_STAMP(2);
@@ -610,7 +623,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         ag_st(f.bar + BAR_GFLAG, 1);
     }
     // (c) my column strip of A^T: rows k of the packed transpose get my RB rows as 8-element (16-byte) pieces
-    {
+    if (f.A) {
         const ScBuf atb = sc_buf(f.pkAt + (long)b * N * f.pk_ld, (size_t)N * f.pk_ld * 2);
         constexpr int P8 = RB / 8;
         for (int e = tid; e < N * P8; e += L0_NT) {
@@ -642,7 +655,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
     L0_STAMP(6);
     bool ok = l0_barrier(a, b, sflag, ep);
     L0_STAMP(7);
-    const bool exact = ag_ld(f.bar + BAR_GRAPH0 + b * BAR_GSTRIDE + 32) == 0;
+    const bool exact = !f.A || ag_ld(f.bar + BAR_GRAPH0 + b * BAR_GSTRIDE + 32) == 0;      // (packed in: bf16 IS the adjacency)
     const float* Arows = f.A + ((long)b * N + r0) * N;             // fp32 fallback operands
     const float* Acols = f.A + (long)b * N * N + r0;
 

@@ -912,8 +912,19 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
 
 int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                     const float* assign_x, const int* num_nodes, const float* dropout, float* ypred,
-                    float* assign_out, void* save, int mode, long long* labels_out) {
+                    float* assign_out, void* save, int mode, long long* labels_out, const PackedAdj* given) {
     SaveLayout sv = layout_save(c, save);
+    if (given) {
+        // the level-0 adjacency arrives as the packed bf16 pair (dp_build_batch_packed) instead of fp32: only the
+        // persistent level-0 kernels multiply straight from it (every other plan wants the fp32 rows somewhere)
+        if (!level0_persistent(c) || !level0_bwd_persistent(c)) {
+            set_error("the packed-adjacency entry needs the persistent level-0 plan (N >= 128, N %% 4 == 0, B * ceil(N / RB) "
+                      "<= CUs, no sync-BN); pass the fp32 adjacency to dp_encoder_forward for this configuration");
+            return q.err = DP_ERR_UNSUPPORTED;
+        }
+        sv.pkA = const_cast<unsigned short*>(given->A);
+        sv.pkAt = const_cast<unsigned short*>(given->At);
+    }
     // the persistent level-0 kernel's barrier block: first thing in the workspace in BOTH walks; zero when the workspace
     // is first used (diffpool_hip.h), self-cleaning afterwards (dp_level0.hip)
     int* l0_bar = q.alloc<int>(level0_bar_ints(c.B));
@@ -1082,8 +1093,16 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
 
 int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const float* x, const float* adj,
                      const float* assign_x, const int* num_nodes, const float* dropout, const float* d_ypred,
-                     const float* d_assign, float* grads, const void* save, int prezeroed) {
+                     const float* d_assign, float* grads, const void* save, int prezeroed, const PackedAdj* given) {
     SaveLayout sv = layout_save(c, (void*)save);
+    if (given) {
+        if (!level0_persistent(c) || !level0_bwd_persistent(c)) {
+            set_error("the packed-adjacency entry needs the persistent level-0 plan (see dp_encoder_forward_packed)");
+            return q.err = DP_ERR_UNSUPPORTED;
+        }
+        sv.pkA = const_cast<unsigned short*>(given->A);
+        sv.pkAt = const_cast<unsigned short*>(given->At);
+    }
     const int B = c.B, P = c.num_pooling;
     // ---- workspace walk
     size_t maxPU = 0, maxPart = 0, maxSK = 0, maxMeans = 0;

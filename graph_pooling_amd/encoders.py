@@ -29,6 +29,39 @@ from .set2set import Set2Set
 
 
 # ----------------------------------------------------------------------------- GraphConv
+class PackedAdjacency:
+    """The level-0 adjacency of a batch in the form the kernels multiply from: bf16 rows `pk` [B, N, ld] of A and `pkt`
+    of A^T (ld = dp_adj_pack_ld(N); the same tensor for a symmetric adjacency), int16 storage.  Written by
+    `DeviceBatchBuilder.build(..., packed=True)` (dp_build_batch_packed) or `PackedAdjacency.from_dense`; accepted in
+    place of the fp32 `adj` by the encoders' forward when the configuration takes the persistent level-0 plan
+    (dp_encoder_forward_packed raises DP_ERR_UNSUPPORTED otherwise).  The reference has no counterpart: its adjacency
+    is always the dense fp32 batch (train.py:197)."""
+
+    def __init__(self, pk: torch.Tensor, pkt: torch.Tensor, num_nodes_padded: int):
+        if pk.dtype != torch.int16 or pkt.dtype != torch.int16 or pk.dim() != 3 or pk.shape != pkt.shape:
+            raise ValueError("pk / pkt: int16 [B, N, ld] tensors of one shape")
+        self.pk, self.pkt = pk, pkt
+        self.B, self.N = int(pk.shape[0]), int(num_nodes_padded)
+        if pk.shape[1] != self.N or pk.shape[2] != _lib.load().dp_adj_pack_ld(self.N):
+            raise ValueError(f"packed rows must be [B, {self.N}, dp_adj_pack_ld({self.N})]")
+
+    @classmethod
+    def from_dense(cls, adj: torch.Tensor) -> "PackedAdjacency":
+        """dp_adj_pack of a dense fp32 batch (every entry must be exactly representable in bf16, e.g. 0/1)."""
+        _lib.require_gpu_tensor(adj, "adj")
+        lib = _lib.load()
+        B, N = int(adj.shape[0]), int(adj.shape[1])
+        ld = lib.dp_adj_pack_ld(N)
+        pk = torch.empty(B, N, ld, device=adj.device, dtype=torch.int16)
+        pkt = torch.empty_like(pk)
+        flag = torch.zeros(64, device=adj.device, dtype=torch.int32)
+        _lib.check(lib.dp_adj_pack(adj.contiguous().float().data_ptr(), pk.data_ptr(), pkt.data_ptr(), flag.data_ptr(),
+                                   B, N, _lib.current_stream()), "dp_adj_pack")
+        if int(flag[0].item()) != 0:
+            raise ValueError("the adjacency has entries that bf16 cannot hold exactly; use the fp32 entry")
+        return cls(pk, pkt, N)
+
+
 class _GraphConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, adj, weight, bias, flags):
@@ -143,12 +176,16 @@ class _EncoderFn(torch.autograd.Function):
                 assign = assign_copy = torch.empty(B, plan.cfg.N, plan.cfg.n_nodes[1], device=x.device,
                                                    dtype=torch.float32)
         stream = _lib.current_stream()
-        _lib.check(lib.dp_encoder_forward(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(), adj.data_ptr(),
-                                          _lib.ptr(assign_x), _lib.ptr(num_nodes), _lib.ptr(drop), ypred.data_ptr(),
-                                          _lib.ptr(assign_copy), _lib.ptr(labels), save.data_ptr(), plan.save_bytes,
-                                          plan.workspace.data_ptr(), plan.ws_bytes,
-                                          _lib.MODE_TRAIN if needs_grad else _lib.MODE_EVAL, stream),
-                   "dp_encoder_forward")
+        tail = (_lib.ptr(assign_x), _lib.ptr(num_nodes), _lib.ptr(drop), ypred.data_ptr(), _lib.ptr(assign_copy),
+                _lib.ptr(labels), save.data_ptr(), plan.save_bytes, plan.workspace.data_ptr(), plan.ws_bytes,
+                _lib.MODE_TRAIN if needs_grad else _lib.MODE_EVAL, stream)
+        if isinstance(adj, PackedAdjacency):
+            _lib.check(lib.dp_encoder_forward_packed(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(),
+                                                     adj.pk.data_ptr(), adj.pkt.data_ptr(), *tail),
+                       "dp_encoder_forward_packed")
+        else:
+            _lib.check(lib.dp_encoder_forward(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(), adj.data_ptr(),
+                                              *tail), "dp_encoder_forward")
         # a training forward cleared the backward accumulators in the plan's workspace: the FIRST backward of the most
         # recent training forward may skip its zero-fill (any other backward clears them itself)
         plan.prezero_owner = ctx if needs_grad else None
@@ -173,11 +210,16 @@ class _EncoderFn(torch.autograd.Function):
         grads = torch.empty(plan.cfg.n_params, device=x.device, dtype=torch.float32)
         prezeroed = 1 if plan.prezero_owner is ctx else 0
         plan.prezero_owner = None
-        _lib.check(lib.dp_encoder_backward(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(), adj.data_ptr(),
-                                           _lib.ptr(assign_x), _lib.ptr(num_nodes), _lib.ptr(drop), d_ypred.data_ptr(),
-                                           _lib.ptr(d_assign), grads.data_ptr(), ctx.save.data_ptr(),
-                                           plan.save_bytes, plan.workspace.data_ptr(), plan.ws_bytes, prezeroed,
-                                           _lib.current_stream()), "dp_encoder_backward")
+        tail = (_lib.ptr(assign_x), _lib.ptr(num_nodes), _lib.ptr(drop), d_ypred.data_ptr(), _lib.ptr(d_assign),
+                grads.data_ptr(), ctx.save.data_ptr(), plan.save_bytes, plan.workspace.data_ptr(), plan.ws_bytes,
+                prezeroed, _lib.current_stream())
+        if isinstance(adj, PackedAdjacency):
+            _lib.check(lib.dp_encoder_backward_packed(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(),
+                                                      adj.pk.data_ptr(), adj.pkt.data_ptr(), *tail),
+                       "dp_encoder_backward_packed")
+        else:
+            _lib.check(lib.dp_encoder_backward(C.byref(plan.cfg), owner._flat.data_ptr(), x.data_ptr(), adj.data_ptr(),
+                                               *tail), "dp_encoder_backward")
         owner._last_flat_grad = grads
         out = [None, None, None, None, None, None, None, None]
         for (off, numel, shape) in owner._flat_index:
@@ -451,11 +493,20 @@ class GcnEncoderGraph(nn.Module):
 
     def _run(self, x, adj, batch_num_nodes, assign_x=None, labels=None):
         _lib.require_gpu_tensor(x, "x")
-        _lib.require_gpu_tensor(adj, "adj")
-        if x.dim() != 3 or adj.dim() != 3 or adj.shape[1] != adj.shape[2] or adj.shape[:2] != x.shape[:2]:
-            raise ValueError(f"expected x [B,N,F] and adj [B,N,N], got {tuple(x.shape)} and {tuple(adj.shape)}")
-        x = x.contiguous().float()
-        adj = adj.contiguous().float()
+        if isinstance(adj, PackedAdjacency):
+            # the level-0 adjacency in the kernels' own bf16 form (DeviceBatchBuilder(packed=True)): no fp32 batch exists
+            if x.dim() != 3 or (adj.B, adj.N) != tuple(x.shape[:2]):
+                raise ValueError(f"expected x [B,N,F] for a packed adjacency of {adj.B} graphs x {adj.N} nodes, got "
+                                 f"{tuple(x.shape)}")
+            if adj.pk.device != x.device:
+                raise ValueError("x and the packed adjacency are on different devices")
+            x = x.contiguous().float()
+        else:
+            _lib.require_gpu_tensor(adj, "adj")
+            if x.dim() != 3 or adj.dim() != 3 or adj.shape[1] != adj.shape[2] or adj.shape[:2] != x.shape[:2]:
+                raise ValueError(f"expected x [B,N,F] and adj [B,N,N], got {tuple(x.shape)} and {tuple(adj.shape)}")
+            x = x.contiguous().float()
+            adj = adj.contiguous().float()
         if assign_x is not None:
             assign_x = assign_x.contiguous().float()
         self._ensure_flat(x.device)
@@ -829,5 +880,7 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
         if self.linkpred:
             if adj is None:
                 raise ValueError("linkpred=True: loss() needs adj (train.py:207 passes it)")
+            if isinstance(adj, PackedAdjacency):
+                raise TypeError("the link-prediction loss reads the dense fp32 adjacency; it has no packed form")
             return _loss(self, pred, label, self.assign_tensor, adj, batch_num_nodes, True)
         return _loss(self, pred, label, None, None, None, False)

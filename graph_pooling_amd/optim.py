@@ -23,11 +23,16 @@ class FusedClipAdam:
     """opt = FusedClipAdam(model, lr=1e-3, clip=2.0);  loss.backward();  opt.step()"""
 
     def __init__(self, model, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
-                 clip: Optional[float] = None):
+                 clip: Optional[float] = None, device_step_counter: bool = False):
+        """device_step_counter: keep Adam's step count in a device int that the update kernel increments and reads
+        (dp_clip_adam_step_counted) instead of passing it from the host — nothing about the call changes from step to
+        step, so `step()` can be captured in a hipGraph (train_step.CapturedTrainStep)."""
         self.model = getattr(model, "model", model)          # accept a DataParallelEncoder wrapper too
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.clip = float(clip) if clip is not None else 0.0
         self.step_count = 0
+        self.device_step_counter = bool(device_step_counter)
+        self.step_dev = None
         self.exp_avg = None
         self.exp_avg_sq = None
         self.total_norm = None
@@ -50,8 +55,8 @@ class FusedClipAdam:
                 flat[off:off + numel].copy_(p.grad.reshape(-1))
         return flat, False
 
-    @torch.no_grad()
-    def step(self):
+    def ensure_state(self):
+        """Allocate the moments / step counter (zeros) for the model's current flat buffer; returns (n, device)."""
         lib = _lib.load()
         m = self.model
         device = next(m.parameters()).device
@@ -63,13 +68,28 @@ class FusedClipAdam:
             self.exp_avg_sq = torch.zeros(n, device=device, dtype=torch.float32)
             self.total_norm = torch.zeros(1, device=device, dtype=torch.float32)
             self._ws = torch.empty(lib.dp_clip_adam_workspace_bytes(), device=device, dtype=torch.uint8)
+            self.step_dev = torch.full((1,), self.step_count, device=device, dtype=torch.int32)
+        return n, device
+
+    @torch.no_grad()
+    def step(self):
+        lib = _lib.load()
+        m = self.model
+        n, device = self.ensure_state()
         grads, aliased = self._flat_grad()
         self.step_count += 1
-        _lib.check(lib.dp_clip_adam_step(m._flat.data_ptr(), grads.data_ptr(), self.exp_avg.data_ptr(),
-                                         self.exp_avg_sq.data_ptr(), n, self.step_count, self.lr, self.betas[0],
-                                         self.betas[1], self.eps, self.clip, self.total_norm.data_ptr(),
-                                         self._ws.data_ptr(), self._ws.numel(), _lib.current_stream()),
-                   "dp_clip_adam_step")
+        if self.device_step_counter:
+            _lib.check(lib.dp_clip_adam_step_counted(m._flat.data_ptr(), grads.data_ptr(), self.exp_avg.data_ptr(),
+                                                     self.exp_avg_sq.data_ptr(), n, self.step_dev.data_ptr(), self.lr,
+                                                     self.betas[0], self.betas[1], self.eps, self.clip,
+                                                     self.total_norm.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                                     _lib.current_stream()), "dp_clip_adam_step_counted")
+        else:
+            _lib.check(lib.dp_clip_adam_step(m._flat.data_ptr(), grads.data_ptr(), self.exp_avg.data_ptr(),
+                                             self.exp_avg_sq.data_ptr(), n, self.step_count, self.lr, self.betas[0],
+                                             self.betas[1], self.eps, self.clip, self.total_norm.data_ptr(),
+                                             self._ws.data_ptr(), self._ws.numel(), _lib.current_stream()),
+                       "dp_clip_adam_step")
         if not aliased:           # keep .grad consistent with what clip_grad_norm_ would have left there
             for p, (off, numel, shape) in zip(m._flat_params, m._flat_index):
                 if p.grad is not None:

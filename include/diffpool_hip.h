@@ -345,6 +345,22 @@ int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const fl
                         const float* d_assign, float* grads, const void* save, size_t save_bytes,
                         void* workspace, size_t workspace_bytes, int prezeroed, void* stream);
 
+/* The same two calls for a level-0 adjacency that is ALREADY in the packed form the kernels multiply from — bf16 rows
+ * [B, N, dp_adj_pack_ld(N)] of A (adj_pk) and of A^T (adj_pkt; the same buffer for a symmetric adjacency), as written
+ * by dp_build_batch_packed or dp_adj_pack: no fp32 [B,N,N] batch is written, read or converted (the
+ * end-to-end training step).  The bf16 values ARE the adjacency (nothing to round).  Only configurations that take the
+ * persistent level-0 plan accept it (N >= 128, N % 4 == 0, B * ceil(N / RB) <= CUs, no sync-BN, no add_self):
+ * DP_ERR_UNSUPPORTED otherwise — the fp32 entries above serve every configuration and train.py.  The link-prediction
+ * loss (dp_loss_forward with linkpred) reads the fp32 adjacency and has no packed form. */
+int dp_encoder_forward_packed(const dp_encoder_cfg* cfg, const float* params, const float* x, const void* adj_pk,
+                              const void* adj_pkt, const float* assign_x, const int* num_nodes, const float* dropout,
+                              float* ypred, float* assign_out, long long* labels_out, void* save, size_t save_bytes,
+                              void* workspace, size_t workspace_bytes, int mode, void* stream);
+int dp_encoder_backward_packed(const dp_encoder_cfg* cfg, const float* params, const float* x, const void* adj_pk,
+                               const void* adj_pkt, const float* assign_x, const int* num_nodes, const float* dropout,
+                               const float* d_ypred, const float* d_assign, float* grads, const void* save,
+                               size_t save_bytes, void* workspace, size_t workspace_bytes, int prezeroed, void* stream);
+
 /* SoftPoolingGcnEncoder.loss (encoders.py:1302-1334): loss_out[0] = CE (+ link), loss_out[1] = link.
  * prob [B,C] saved for backward.  S / adj may be NULL when linkpred == 0.
  * d_ypred_unit [B,C] (may be NULL): d loss / d ypred for an upstream gradient of 1, (softmax - onehot) / B, written by
@@ -380,6 +396,19 @@ int dp_build_batch(const int* edge_src, const int* edge_dst, const int* edge_ptr
                    int* degree, int B, int N, int F, int feature_mode, int symmetric, int max_edges_per_graph,
                    void* stream);
 
+/* The same builder writing the adjacency straight into the packed form of dp_adj_pack (bf16 rows, ld =
+ * dp_adj_pack_ld(N); 1.0 = 0x3F80): adj_pk receives A, adj_pkt receives A^T — for symmetric != 0 the two are equal
+ * and the caller may pass the SAME buffer for both (dp_adj_pack_bytes(B, N) bytes each).  Feeds
+ * dp_encoder_forward_packed / _backward_packed: the fp32 [B,N,N] batch is never materialised. */
+int dp_build_batch_packed(const int* edge_src, const int* edge_dst, const int* edge_ptr, const int* node_label,
+                          const int* node_ptr, void* adj_pk, void* adj_pkt, float* feats, float* assign_feats,
+                          int* num_nodes, int* errors, int* degree, int B, int N, int F, int feature_mode, int symmetric,
+                          int max_edges_per_graph, void* stream);
+/* The input arrays of both builders may live in pinned host memory that the device can address (hipHostMalloc): the
+ * kernels then fetch the ~190 KB of a DD batch over PCIe themselves and a captured training step needs no copy node.
+ * dp_gather_labels copies the B graph labels the same way (int64, host-visible source -> device). */
+int dp_gather_labels(const long long* graph_label, long long* label_out, int B, void* stream);
+
 /* ------------------------------------------------------------------ N2  fused gradient clip + Adam step
  * train.py:209-210 on top of the Adam of train.py:173, over the flat fp32 parameter / gradient buffers (n floats):
  *   total = ||grads||_2;  grads *= min(1, max_norm / (total + 1e-6))   (max_norm <= 0: no clipping)
@@ -390,6 +419,14 @@ size_t dp_clip_adam_workspace_bytes(void);
 int dp_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, int step, float lr,
                       float beta1, float beta2, float eps, float max_norm, float* total_norm_out, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* The same update with the step count kept ON THE DEVICE: step_counter (device int, the number of updates done so far;
+ * zero it once) is incremented by the call and the bias corrections of the new count are computed by the kernel (in
+ * double, as above).  No argument changes from step to step, so the call can sit inside a captured hipGraph together
+ * with dp_build_batch_packed, dp_encoder_forward_packed, dp_loss_forward and dp_encoder_backward_packed: one graph
+ * launch per training step (train.py:197-210). */
+int dp_clip_adam_step_counted(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, int* step_counter,
+                              float lr, float beta1, float beta2, float eps, float max_norm, float* total_norm_out,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

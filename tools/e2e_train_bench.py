@@ -69,7 +69,27 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / args.steps * 1e3
 
+    def run_captured():
+        """build -> forward -> loss -> backward -> clip + Adam as ONE hipGraph launch per step (train_step.py)."""
+        from graph_pooling_amd.train_step import CapturedTrainStep
+        torch.manual_seed(0)
+        model = SoftPoolingGcnEncoder(N, F_, H, H, Cc, 3, H, assign_ratio=0.1, linkpred=False).cuda()
+        opt = FusedClipAdam(model, lr=1e-3, clip=2.0, device_step_counter=True)
+        builder = DeviceBatchBuilder(EdgeListDataset.from_tu_graphs(graphs), N, F_, dev)
+        step = CapturedTrainStep(model, opt, builder, B)
+        for i in range(10):
+            step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps * 1e3
+        assert step.skipped_entries() == 0
+        return dt
+
     out = {arm: round(run(arm), 3) for arm in ("reference-style", "device-builder+fused-optimizer")}
+    out["captured: packed builder + model + fused optimizer in one hipGraph"] = round(run_captured(), 3)
     out["unit"] = "ms per training step (B=20, N_max=500, F=89), eager, host loop included"
     print(json.dumps(out))
 
