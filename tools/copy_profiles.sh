@@ -12,6 +12,7 @@ cp $O/pmc_er_probe_summary.csv $D/${P}_er_probe_pmc_summary.csv
 cp $O/step_trace_dd.txt $D/${P}_dd_step_trace.txt
 cp $O/pmc_dd_step_summary.csv $D/${P}_dd_step_pmc_summary.csv
 for s in l0 l0b s2s; do [ -f $O/${s}_stamps.txt ] && grep -v amdgpu.ids $O/${s}_stamps.txt > $D/${P}_${s}_stamps.txt; done
+[ -f $O/e2e_train_bench.json ] && cp $O/e2e_train_bench.json $D/${P}_e2e_train_bench.json
 [ -f $O/gemm_split_probe.txt ] && cp $O/gemm_split_probe.txt $D/${P}_gemm_split_probe.txt
 [ -f gpurun_out/er_breakdown/kernels.txt ] && cp gpurun_out/er_breakdown/kernels.txt $D/${P}_er_step_kernels.txt
 [ -f gpurun_out/er_breakdown/gemm_shapes.txt ] && cp gpurun_out/er_breakdown/gemm_shapes.txt $D/${P}_er_step_gemm_shapes.txt

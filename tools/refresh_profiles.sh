@@ -17,6 +17,7 @@ timeout -k 10 200 python3 bench.py --no-cpu-baseline --workload enzymes_p3 > $O/
 DP_LIB=graph_pooling_amd/libdiffpool_hip_stamp.so PYTHONPATH=. timeout -k 10 120 python3 tools/l0_stamps.py > $O/l0_stamps.txt 2>&1 || true
 DP_LIB=graph_pooling_amd/libdiffpool_hip_stamp.so PYTHONPATH=. timeout -k 10 120 python3 tools/l0b_stamps.py > $O/l0b_stamps.txt 2>&1 || true
 DP_LIB=graph_pooling_amd/libdiffpool_hip_stamp.so PYTHONPATH=. timeout -k 10 120 python3 tools/s2s_stamps.py > $O/s2s_stamps.txt 2>&1 || true
+PYTHONPATH=. timeout -k 10 300 python3 tools/e2e_train_bench.py > $O/e2e_train_bench.json 2>/dev/null || true
 echo benches done
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dd -o dd -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/prof_dd.log 2>&1
