@@ -230,7 +230,7 @@ __device__ __forceinline__ void sg_store(unsigned short* __restrict__ img, const
 // BN = 128, or 64 for products with a narrow output (N <= 64: the pooling products X' = S^T Z, dZ += S dX' at 60
 // columns): the waves then stack along M only (NW x 1, 128 / NW rows x 64 columns each).
 template <bool TA, bool TB, int NW, int BN>
-__device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsigned short* lds) {
+__device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, int b, unsigned short* lds) {
     constexpr int NT = NW * 64;
     constexpr int WC = BN / 64;                 // wave columns: 2 or 1
     constexpr int WR = NW / WC;                 // wave rows
@@ -238,7 +238,6 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
     constexpr int NQ = 1024 / NT;               // quads per thread and 128-row operand slab
     constexpr int NQB = NQ * BN / 128;          // ... and B slab
     constexpr int PLANE_B = BN * SG_LDK;
-    const int b = blockIdx.y;
     const int m0 = (tile / a.tilesN) * SG_BM, n0 = (tile % a.tilesN) * BN;
     const float* A = a.A + (long)b * a.sA;
     const float* B = a.B + (long)b * a.sB;
@@ -372,13 +371,20 @@ __device__ __forceinline__ void sg_body(const SplitGemmArgs& a, int tile, unsign
 template <int NW, int BN = SG_BN>
 __global__ __launch_bounds__(NW * 64) void k_gemm_split_bf16(SplitGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short sg_lds[];
-    const int tile = blockIdx.x;
+    // XCD-aware work mapping (as k_aggregate): workgroups are dealt to the 8 XCDs round-robin in dispatch order, each XCD
+    // with its own L2.  The tiles of ONE batch element read the same operand panels (every A panel tilesN times, every B
+    // panel tilesM times): give each XCD a contiguous run of (batch, tile) items so those re-reads hit its L2 instead of
+    // going to HBM a second time from another XCD.
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = lin & 7, idx = lin >> 3, qd = nwg >> 3, rm = nwg & 7;
+    const int w = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    const int tile = w % (int)gridDim.x, b = w / (int)gridDim.x;
     if (a.tA) {
-        if (a.tB) sg_body<true, true, NW, BN>(a, tile, sg_lds);
-        else sg_body<true, false, NW, BN>(a, tile, sg_lds);
+        if (a.tB) sg_body<true, true, NW, BN>(a, tile, b, sg_lds);
+        else sg_body<true, false, NW, BN>(a, tile, b, sg_lds);
     } else {
-        if (a.tB) sg_body<false, true, NW, BN>(a, tile, sg_lds);
-        else sg_body<false, false, NW, BN>(a, tile, sg_lds);
+        if (a.tB) sg_body<false, true, NW, BN>(a, tile, b, sg_lds);
+        else sg_body<false, false, NW, BN>(a, tile, b, sg_lds);
     }
 }
 
