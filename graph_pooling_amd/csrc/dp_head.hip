@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* feat = a.hid[0] + (long)b * a.dims[0];
     HEAD_STAMP(0);
-    // (1) readout loads go out first (8 rows per thread in flight, clamped addresses, no branches) ...
-    constexpr int RU = 8;
+    // (1) readout loads go out first (16 rows per thread in flight: one pass for a level of <= 64 nodes, clamped addresses, no branches) ...
+    constexpr int RU = 16;
     float zv[RU];
     const bool one_pass = a.Z && a.rw <= 64 && a.n <= 4 * RU;
     if (one_pass) {
