@@ -16,4 +16,5 @@ for r in rows[a:b]:
     if d >= thresh_us:
         print(f"{r['Kernel_Name'][:64]:64s} grid={r['Grid_Size_X']:>8s},{r['Grid_Size_Y']:>4s} wg={r['Workgroup_Size_X']:>4s} us={d:9.2f}")
 span = (int(rows[b]['Start_Timestamp']) - int(rows[a]['Start_Timestamp'])) / 1e3
-print(f"{b - a} launches, {tot:.1f} us of kernel time, {span:.1f} us from this step's first kernel to the next step's")
+print(f"{b - a} launches, {tot:.1f} us of kernel time ({span:.1f} us between two steps' first kernels UNDER THE PROFILER, "
+      f"which serialises graph replays; the unprofiled step time is bench.py's ms_per_step)")
