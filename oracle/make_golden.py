@@ -21,6 +21,7 @@ Everything else — gcn_forward, apply_bn, construct_mask, forward, loss, Set2Se
 MeanAggregator — is the reference's code executing.  Fixtures hold inputs,
 parameters by state_dict key, outputs and gradients; never reference source.
 """
+import hashlib
 import os
 import random
 import sys
@@ -47,12 +48,20 @@ import set2set as RS            # noqa: E402
 import aggregators as RA        # noqa: E402
 
 # ---- P2
+REFERENCE_GRAPHCONV_SHA256 = "ca676c074e6668c76bc7b9911fc59a4f3095303ead5ecffe79ed4591737fee40"
+
+
 def reference_graphconv():
     """The DiffPool GraphConv as the reference wrote it (encoders.py:944-974, a comment block): un-commented in
     memory and exec'd inside the imported module's namespace (torch / nn / F / init as the reference imported them)."""
     with open(os.path.join(REF, "encoders.py")) as f:
         lines = f.read().split("\n")[943:974]
     assert lines[1].startswith("# class GraphConv(nn.Module):") and lines[-1].strip() == "#         return y", lines
+    # the block is text of an untrusted file about to be executed: it must be, byte for byte, the 31 lines that were
+    # read and reviewed when the fixtures were first made (a GraphConv class: __init__ + forward, nothing else)
+    digest = hashlib.sha256("\n".join(lines).encode()).hexdigest()
+    if digest != REFERENCE_GRAPHCONV_SHA256:
+        raise SystemExit(f"encoders.py:944-974 changed (sha256 {digest}); review it before regenerating the fixtures")
     text = "\n".join(l[2:] if l.startswith("# ") else l[1:] for l in lines)
     ns = dict(vars(R))
     exec(compile(text, "<encoders.py:944-974 un-commented>", "exec"), ns)
