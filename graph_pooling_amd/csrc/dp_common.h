@@ -34,6 +34,28 @@ int device_error_gate(const char* entry);     // DP_OK, or DP_ERR_DEVICE (+ mess
 __device__ inline void dev_err_raise(int* word, int bit) {
     if (word) __hip_atomic_fetch_or(word, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+
+// ---- write-through / L1-bypassing access to what other workgroups of the SAME launch write or read (raw buffer
+// builtins, aux 16 = sc1: stores go through to memory, loads do not trust this XCD's L2), and the tagged 16-byte entry
+// {v0, tag, v1, tag} of the barrier-free BatchNorm exchange (dp_level0.hip "tagged entries", dp_small.hip).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct ScBuf {
+    __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ ScBuf sc_buf(const void* p, size_t bytes) {
+    return ScBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)};
+}
+__device__ __forceinline__ u32x4 sc_ld16(ScBuf b, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 16); }
+__device__ __forceinline__ void sc_st16(ScBuf b, unsigned off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, b.r, off, 0, 16); }
+__device__ __forceinline__ float sc_ldf(ScBuf b, unsigned off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.r, off, 0, 16));
+}
+__device__ __forceinline__ void sc_stf(ScBuf b, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b.r, off, 0, 16);
+}
+__device__ __forceinline__ u32x4 sc_tagged(float v0, float v1, unsigned tag) {
+    return (u32x4){__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+}
 #endif
 
 // ----------------------------------------------------------------- workgroup barrier for LDS hazards only
@@ -112,6 +134,9 @@ struct Seq {
     // Whoever sets it must let a GEMM follow before the region's first reader (bgemm_group consumes and clears it).
     void* fold_zero_p = nullptr;
     int fold_zero_n16 = 0;
+    // launch sequence number of the kernels that exchange tagged entries (a word of the workspace's first block, zero
+    // once, counted up by every such launch): set by the model-level walks
+    int* seq_word = nullptr;
 
     Seq(hipStream_t s, void* w, size_t wb) : stream(s), ws((char*)w), ws_bytes(wb), ws_off(0), err(0), dry(false) {}
     static Seq sizing() {
@@ -399,7 +424,7 @@ struct SmallLevelIO {
     int ldz;
     int coff[DP_MAX_LAYERS];
     float* part;                   // exchange scratch, small_level_part_floats() floats
-    int* bar;                      // 2 ints: ticket (zeroed in stream order before the launch), error word
+    int* bar;                      // [0] spare, [1] error word, [2] finish ticket (zeroed in stream order before the launch)
 };
 bool small_level_fused_ok(int B, int n, const int* dims, int L, bool dadj);
 size_t small_level_part_floats(int B, int n, int L);
@@ -496,6 +521,7 @@ size_t level0_bwd_gpart_floats(const Level0Bwd& a);
 void level0_backward(Seq& q, const Level0Bwd& a);
 bool level0_persistent_ok(const Level0Fwd& a);
 size_t level0_bar_ints(int B);
+int* level0_seq_word(int* bar);
 size_t level0_xpart_floats(const Level0Fwd& a);
 size_t level0_vs_elems(const Level0Fwd& a);
 size_t level0_part_floats(const Level0Fwd& a);

@@ -15,8 +15,8 @@
 //   * the operand of an aggregation U = A_rows . P needs ALL rows of P of the graph: each workgroup writes the exact
 //     3-plane bf16 split of its rows (the layout dp_agg.hip reads), then a PER-GRAPH barrier (T arrivals);
 //   * apply_bn couples the graphs, but only at equal node index (statistics per node index over batch x features): row
-//     partials (mean, M2), then a COLUMN barrier over the B workgroups that hold the same row block (one counter per row
-//     block; the first build used a grid-wide barrier here — two chained atomics and 220 workgroups' stragglers);
+//     partials (mean, M2) travel as TAGGED 16-byte entries that the B workgroups holding the same row block poll — no
+//     barrier at all (l0_poll_entries; the first builds used a grid-wide, then a per-row-block barrier here);
 //   * X' = S^T Z and A' = Tt^T S contract over the node index: per-workgroup partial tiles, a per-graph barrier, then
 //     the graph's workgroups sum disjoint slices in block order (deterministic); the max readout likewise.
 // Barrier counters only grow inside a launch (the e-th crossing waits for e * arrivals; nothing is reset between
@@ -59,7 +59,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
@@ -75,26 +74,10 @@ constexpr float L0_BN_EPS = 1e-5f;
 constexpr int L0_SPIN_LIMIT = 1 << 22;
 
 // barrier block (ints; every word that is polled or added to sits on a 64-byte line of its own)
-constexpr int BAR_GCOUNT = 0, BAR_DONE = 32, BAR_GFLAG = 48, BAR_ERR = 64, BAR_GRAPH0 = 128;
+constexpr int BAR_GCOUNT = 0, BAR_DONE = 32, BAR_GFLAG = 48, BAR_ERR = 64, BAR_SEQ = 96, BAR_GRAPH0 = 128;
 constexpr int BAR_GSTRIDE = 48;       // per graph: +0 count, +16 generation, +32 "adjacency not bf16-exact"
-constexpr int BAR_CSTRIDE = 32;       // per row block (after the graphs' entries): the BatchNorm column counter
-constexpr int BAR_MAX_T = 256;        // row blocks per graph <= CUs / B
 
 // ---- write-through / L1-bypassing access to what other workgroups of this launch write or read
-struct ScBuf {
-    __amdgpu_buffer_rsrc_t r;
-};
-__device__ __forceinline__ ScBuf sc_buf(const void* p, size_t bytes) {
-    return ScBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)};
-}
-__device__ __forceinline__ u32x4 sc_ld16(ScBuf b, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 16); }
-__device__ __forceinline__ void sc_st16(ScBuf b, unsigned off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, b.r, off, 0, 16); }
-__device__ __forceinline__ float sc_ldf(ScBuf b, unsigned off) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.r, off, 0, 16));
-}
-__device__ __forceinline__ void sc_stf(ScBuf b, unsigned off, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b.r, off, 0, 16);
-}
 __device__ __forceinline__ int ag_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ag_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ag_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -183,10 +166,9 @@ __device__ inline void l0_mma(const float* A, int lda, const float* B, int ldb, 
 
 // ---- barriers.  Every thread calls; returns false once a wait of this workgroup has given up (sticky).
 // Counters only ever grow inside a launch (the last workgroup to FINISH clears them): the e-th graph barrier of a
-// launch waits for the graph's counter to reach e * T, the e-th column barrier for the row block's counter to reach
-// e * B.  `epoch` = crossings so far of each kind, kept by the caller.
+// launch waits for the graph's counter to reach e * T.  `epoch` = crossings so far, kept by the caller.
 struct L0Epoch {
-    int graph, grid, col;
+    int graph;
 };
 template <typename Args>
 __device__ inline bool l0_barrier(const Args& a, int b, int* sflag /*LDS: [0] ok, [1] failed (sticky)*/, L0Epoch& ep) {
@@ -218,37 +200,49 @@ __device__ inline bool l0_barrier(const Args& a, int b, int* sflag /*LDS: [0] ok
     return sflag[0] != 0;
 }
 
-// BatchNorm's exchange is between the workgroups that hold the SAME row block of the B graphs (statistics are per node
-// index over the batch, encoders.py:1048-1052): a barrier over those B workgroups only — one counter per row block, one
-// atomic per arrival, nobody waits for another row block's straggler.  It says nothing about the other row blocks of
-// the caller's graph (the graph barriers do).  Same monotonic-counter scheme: the e-th crossing waits for e * B.
-template <typename Args>
-__device__ inline bool l0_col_barrier(const Args& a, int rb, int* sflag, L0Epoch& ep) {
-    ep.col += 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int ok = sflag[1] ? 0 : 1;
-        int* cc = a.f.bar + BAR_GRAPH0 + a.f.B * BAR_GSTRIDE + rb * BAR_CSTRIDE;
-        const int target = ep.col * a.f.B + a.target_bias;
-        ag_add(cc, 1);
-        if (ok) {
-            int it = 0;
-            while (ag_ld(cc) < target) {
-                if (++it > a.spin_limit) {
-                    ok = 0;
-                    ag_st(a.f.bar + BAR_ERR, 1);
-                    dev_err_raise(a.dev_err, DP_DEVERR_BARRIER);
-                    break;
+// ---- BatchNorm exchange without a barrier: tagged entries (the scheme of RCCL's LL protocol).
+// A row's partial pair travels as ONE 16-byte write-through store {v0, tag, v1, tag}; tag = (launch sequence number,
+// layer), different in every launch and layer and never 0 (the sequence number lives in the barrier block, read by
+// everybody at kernel start and counted up by the last workgroup to finish).  A reader polls the entries it needs with
+// 16-byte sc1 loads until both tags of each are this launch's: the data is its own "ready" flag — no arrival counter,
+// no acknowledgement wait on the producer's side, and one memory round trip on the consumer's instead of two (poll the
+// counter, then load).  Each 8-byte half carries its own tag, so an entry torn at 8 bytes cannot be mistaken for a
+// whole one.  Bounded like the barriers.
+// NI items per thread, L0_BPAIRS graph slots per item: entry (item j, slot u) at byte offset off[j] + 16 * min(tl + 16 u, B - 1)
+template <int NI, typename Args>
+__device__ __forceinline__ bool l0_poll_entries(const Args& a, ScBuf buf, const unsigned (&off)[NI], int B, unsigned tag,
+                                                float (&v0)[NI][L0_BPAIRS], float (&v1)[NI][L0_BPAIRS], int* sflag) {
+    const int tl = threadIdx.x & 15;
+    const unsigned want = tag ^ (a.target_bias ? 0x40000000u : 0u);      // (test knob: a tag nobody writes)
+    int it = 0;
+    for (;;) {
+        bool ready = true;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+#pragma unroll
+            for (int u = 0; u < L0_BPAIRS; ++u) {
+                if (16 * u < B) {                                               // (uniform)
+                    const u32x4 q = sc_ld16(buf, off[j] + 16u * (unsigned)min(tl + 16 * u, B - 1));
+                    v0[j][u] = __uint_as_float(q[0]);
+                    v1[j][u] = __uint_as_float(q[2]);
+                    ready = ready && q[1] == want && q[3] == want;
+                } else {
+                    v0[j][u] = 0.f;
+                    v1[j][u] = 0.f;
                 }
-                __builtin_amdgcn_s_sleep(1);
             }
         }
-        sflag[0] = ok;
-        if (!ok) sflag[1] = 1;
+        if (__all(ready)) return true;
+        if (++it > a.spin_limit || sflag[1]) {
+            if (!sflag[1]) {
+                sflag[1] = 1;
+                ag_st(a.f.bar + BAR_ERR, 1);
+                dev_err_raise(a.dev_err, DP_DEVERR_BARRIER);
+            }
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
     }
-    __syncthreads();
-    return sflag[0] != 0;
 }
 
 // Bulk copy global -> LDS of `count` floats (4-byte aligned source): every thread asks for all its 16-byte quads before
@@ -520,7 +514,8 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
     float* BIAS = lds + a.lds_scr + a.scr_floats;          // every layer's biases [l][g][64], then assign_pred's [64]
     int* sflag = reinterpret_cast<int*>(BIAS + (2 * DP_MAX_LAYERS + 1) * 64);   // [0] ok, [1] failed, [2] block flag, [3] last
     if (tid < 4) sflag[tid] = 0;
-    L0Epoch ep{0, 0, 0};
+    L0Epoch ep{0};
+    const unsigned seq = (unsigned)f.bar[BAR_SEQ];          // launch sequence number (stable until the last workgroup finishes)
 
     // Exchange buffers are WRITE-ONCE per launch (one region per pass): a reader can only ever fetch a line after its
     // writers are done, so no cache of this launch can hold a stale copy and the reads are ordinary cached loads (the
@@ -687,7 +682,8 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
         L0_STAMP(9 + 8 * l);
         // tail: + bias, l2-normalise, save, BatchNorm partials — one 16-lane team per (row, group); y also goes to the
         // layer's slice of the LDS activation rows (BatchNorm rewrites it in place after the exchange)
-        const ScBuf partw = sc_buf(f.part + (long)l * f.B * N * G * 2, (size_t)f.B * N * G * 2 * sizeof(float));
+        const ScBuf partw = sc_buf(f.part + (long)l * f.B * N * G * 4, (size_t)f.B * N * G * 4 * sizeof(float));
+        const unsigned bn_tag = (seq << 4) | (unsigned)(l + 1);
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             float yv[L0_NK];
@@ -739,39 +735,31 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
                     }
                 }
                 m2 = row16_sum(m2);
-                if (on && tl == 0) {               // [node][group][graph][2]: a node's B pairs are contiguous for the reader
-                    const long po = ((((long)min(r0 + r, N - 1) * G + g) * f.B + b) * 2) * 4;
-                    sc_stf(partw, (unsigned)po, mean);
-                    sc_stf(partw, (unsigned)(po + 4), m2);
+                if (on && tl == 0) {               // [node][group][graph]: a node's B entries are contiguous for the reader
+                    const long po = (((long)min(r0 + r, N - 1) * G + g) * f.B + b) * 16;
+                    sc_st16(partw, (unsigned)po, sc_tagged(mean, m2, bn_tag));
                 }
             }
         }
         L0_STAMP(10 + 8 * l);
         if (last) break;
-        // ---- apply_bn: every graph's partials of my node indices (grid barrier), then x = (relu(y) - mu) * rstd
-        if (f.bn) ok = l0_col_barrier(a, rb, sflag, ep) && ok;
-        else lds_barrier();
+        // ---- apply_bn: every graph's partials of my node indices (tagged entries, polled), then x = (relu(y) - mu) * rstd
+        if (!f.bn) lds_barrier();
         L0_STAMP(11 + 8 * l);
         const int ctn = f.st[0].dims[l + 2] + (G == 2 ? f.st[1].dims[l + 2] : 0);
         float* PTn = Wn1 + ((wn1 + 3) & ~3);               // behind the weights (which sit behind the reduce slots)
         {
-            // all the partials of all my items first (one round trip), then the combines
-            const float* partr = f.part + (long)l * f.B * N * G * 2;
+            // all the partials of all my items in one polled round, then the combines
             float pm[ITEMS][L0_BPAIRS], pq[ITEMS][L0_BPAIRS];
             if (f.bn) {
+                unsigned off[ITEMS];
 #pragma unroll
                 for (int j = 0; j < ITEMS; ++j) {
                     const int it = team + j * L0_TEAMS;
                     const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
-                    const int node = min(r0 + r, N - 1);
-#pragma unroll
-                    for (int u = 0; u < L0_BPAIRS; ++u) {
-                        const float2 pr = *reinterpret_cast<const float2*>(
-                            partr + ((((long)node * G + g) * f.B) + min(tl + 16 * u, f.B - 1)) * 2);
-                        pm[j][u] = pr.x;
-                        pq[j][u] = pr.y;
-                    }
+                    off[j] = (unsigned)((((long)min(r0 + r, N - 1) * G + g) * f.B) * 16);
                 }
+                ok = l0_poll_entries<ITEMS>(a, partw, off, f.B, bn_tag, pm, pq, sflag) && ok;
             }
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
@@ -1057,11 +1045,11 @@ __global__ __launch_bounds__(L0_NT) void k_level0_fwd(L0Args a) {
             ag_st(f.bar + BAR_GRAPH0 + g * BAR_GSTRIDE, 0);
             ag_st(f.bar + BAR_GRAPH0 + g * BAR_GSTRIDE + 32, 0);
         }
-        for (int t = tid; t < a.T; t += L0_NT) ag_st(f.bar + BAR_GRAPH0 + f.B * BAR_GSTRIDE + t * BAR_CSTRIDE, 0);
         if (tid == 0) {
             ag_st(f.bar + BAR_GCOUNT, 0);
             ag_st(f.bar + BAR_GFLAG, 0);
             ag_st(f.bar + BAR_DONE, 0);
+            ag_st(f.bar + BAR_SEQ, (int)((seq + 1u) & 0x03ffffffu));
         }
     }
 }
@@ -1179,7 +1167,8 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
     float* EXT = SCR + a.slots_floats;
     int* sflag = reinterpret_cast<int*>(SCR + a.scr_floats);
     if (tid < 4) sflag[tid] = 0;
-    L0Epoch ep{0, 0, 0};
+    L0Epoch ep{0};
+    const unsigned seq = (unsigned)f.bar[BAR_SEQ];          // launch sequence number (stable until the last workgroup finishes)
     const bool exact = f.pk_flag[0] == 0;
     const int D = f.ldz[0], Da = f.ldz[1], K = f.K;
     const float* Arows = f.A + ((long)b * N + r0) * N;
@@ -1316,20 +1305,17 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
         // ---- BatchNorm-backward means of my node indices: every graph's (sum dx, sum dx xhat) partials -> (m0, m1) in LDS
         float* M01 = EXT;                                  // [RB * G][2]
         if (has_bn) {
-            const float* partr = f.part + (long)l * f.B * N * G * 2;
+            const ScBuf partr = sc_buf(f.part + (long)l * f.B * N * G * 4, (size_t)f.B * N * G * 4 * sizeof(float));
             float p0[ITEMS][L0_BPAIRS], p1[ITEMS][L0_BPAIRS];
+            {
+                unsigned off[ITEMS];
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                const int it = team + j * L0_TEAMS;
-                const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
-                const int node = min(r0 + r, N - 1);
-#pragma unroll
-                for (int u = 0; u < L0_BPAIRS; ++u) {
-                    const float2 pr = *reinterpret_cast<const float2*>(
-                        partr + ((((long)node * G + g) * f.B) + min(tl + 16 * u, f.B - 1)) * 2);
-                    p0[j][u] = pr.x;
-                    p1[j][u] = pr.y;
+                for (int j = 0; j < ITEMS; ++j) {
+                    const int it = team + j * L0_TEAMS;
+                    const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+                    off[j] = (unsigned)((((long)min(r0 + r, N - 1) * G + g) * f.B) * 16);
                 }
+                ok = l0_poll_entries<ITEMS>(a, partr, off, f.B, (seq << 4) | (unsigned)(l + 1), p0, p1, sflag) && ok;
             }
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
@@ -1524,7 +1510,7 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
         if (G == 2) l0_put_compact(gp, a.cw[1][l], STG1, d1 * w1);
         if (l > 0 && f.bn) {
             // BatchNorm-backward partials of layer l - 1: (sum dx, sum dx * xhat) per (row, group); xhat = the layer input
-            const ScBuf partw = sc_buf(f.part + (long)(l - 1) * f.B * N * G * 2, (size_t)f.B * N * G * 2 * sizeof(float));
+            const ScBuf partw = sc_buf(f.part + (long)(l - 1) * f.B * N * G * 4, (size_t)f.B * N * G * 4 * sizeof(float));
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 const int it = team + j * L0_TEAMS;
@@ -1544,16 +1530,13 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                 s0 = row16_sum(s0);
                 s1 = row16_sum(s1);
                 if (on && tl == 0) {
-                    const long po = ((((long)min(r0 + r, N - 1) * G + g) * f.B + b) * 2) * 4;
-                    sc_stf(partw, (unsigned)po, s0);
-                    sc_stf(partw, (unsigned)(po + 4), s1);
+                    const long po = (((long)min(r0 + r, N - 1) * G + g) * f.B + b) * 16;
+                    sc_st16(partw, (unsigned)po, sc_tagged(s0, s1, (seq << 4) | (unsigned)l));      // tag of layer l - 1
                 }
             }
             L0B_STAMP(14 + 8 * (L - 1 - l));
-            ok = l0_col_barrier(a, rb, sflag, ep) && ok;
-        } else {
-            lds_barrier();
         }
+        lds_barrier();
         L0B_STAMP(15 + 8 * (L - 1 - l));
     }
     // ------------------------------------------------------------------ the graph's parameter gradients: one slab row
@@ -1597,10 +1580,10 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
     lds_barrier();
     if (sflag[3]) {
         for (int g = tid; g < f.B; g += L0_NT) ag_st(f.bar + BAR_GRAPH0 + g * BAR_GSTRIDE, 0);
-        for (int t = tid; t < a.T; t += L0_NT) ag_st(f.bar + BAR_GRAPH0 + f.B * BAR_GSTRIDE + t * BAR_CSTRIDE, 0);
         if (tid == 0) {
             ag_st(f.bar + BAR_GCOUNT, 0);
             ag_st(f.bar + BAR_DONE, 0);
+            ag_st(f.bar + BAR_SEQ, (int)((seq + 1u) & 0x03ffffffu));
         }
     }
 }
@@ -1730,7 +1713,7 @@ void l0_launch(Seq& q, const L0Args& a, size_t lds_bytes) {
 
 }  // namespace
 
-size_t level0_bar_ints(int B) { return (size_t)BAR_GRAPH0 + (size_t)BAR_GSTRIDE * B + (size_t)BAR_CSTRIDE * BAR_MAX_T; }
+size_t level0_bar_ints(int B) { return (size_t)BAR_GRAPH0 + (size_t)BAR_GSTRIDE * B; }
 // write-once exchange regions: one split operand per aggregation pass, one partial block per BatchNorm layer
 static void l0_vs_layout(const Level0Fwd& f, long (&off)[DP_MAX_LAYERS + 1], size_t& total) {
     const int K8 = ((f.N + 31) / 32) * 4;
@@ -1750,8 +1733,9 @@ size_t level0_vs_elems(const Level0Fwd& f) {
     l0_vs_layout(f, off, total);
     return total + 64;
 }
-size_t level0_part_floats(const Level0Fwd& f) { return (size_t)(f.L > 1 ? f.L - 1 : 1) * f.B * f.N * f.G * 2 + 4; }
+size_t level0_part_floats(const Level0Fwd& f) { return (size_t)(f.L > 1 ? f.L - 1 : 1) * f.B * f.N * f.G * 4 + 4; }
 const int* level0_error_word(const int* bar) { return bar + BAR_ERR; }
+int* level0_seq_word(int* bar) { return bar + BAR_SEQ; }
 size_t level0_xpart_floats(const Level0Fwd& f) {
     L0Geom g;
     if (!l0_geometry(f, g)) return 4;
@@ -1948,7 +1932,7 @@ size_t level0_bwd_vs_elems(const Level0Bwd& f) {
     l0b_vs_layout(f, off, total);
     return total + 64;
 }
-size_t level0_bwd_part_floats(const Level0Bwd& f) { return (size_t)(f.L > 1 ? f.L - 1 : 1) * f.B * f.N * f.G * 2 + 4; }
+size_t level0_bwd_part_floats(const Level0Bwd& f) { return (size_t)(f.L > 1 ? f.L - 1 : 1) * f.B * f.N * f.G * 4 + 4; }
 size_t level0_bwd_gpart_floats(const Level0Bwd& f) {
     L0BGeom g;
     if (!l0b_geometry(f, g)) return 4;

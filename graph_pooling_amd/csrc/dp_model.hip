@@ -928,6 +928,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
     // the persistent level-0 kernel's barrier block: first thing in the workspace in BOTH walks; zero when the workspace
     // is first used (diffpool_hip.h), self-cleaning afterwards (dp_level0.hip)
     int* l0_bar = q.alloc<int>(level0_bar_ints(c.B));
+    q.seq_word = level0_seq_word(l0_bar);
     const BwdZero bz = alloc_bwd_zero(q, c);      // same offsets as in encoder_backward: next block of the workspace
     Scratch sc = fwd_scratch(q, c);
     if (q.err) return q.err;
@@ -1108,6 +1109,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     size_t maxPU = 0, maxPart = 0, maxSK = 0, maxMeans = 0;
     // (the forward's barrier block, then) zero-initialised gradient accumulators + slabs: ONE block (alloc_bwd_zero)
     int* l0_bar = q.alloc<int>(level0_bar_ints(c.B));
+    q.seq_word = level0_seq_word(l0_bar);
     const BwdZero bz = alloc_bwd_zero(q, c);
     const bool l0_persist = level0_bwd_persistent(c);
     unsigned short* l0_vs = nullptr;

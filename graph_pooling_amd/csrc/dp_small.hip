@@ -480,58 +480,60 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
 // One workgroup per graph keeps the level's adjacency, every layer's weights and the running activations in LDS
 // across the layers; the only thing that crosses workgroups is apply_bn (encoders.py:1048-1052: statistics per node
 // index over batch x features), which needs every graph's row partials between two layers.  They travel through
-// global memory behind a GRID BARRIER: B <= (CUs / 2) workgroups of 1024 threads are co-resident by construction
-// (one per CU), so a ticket barrier cannot deadlock — and it is bounded anyway: a workgroup that waits longer than
-// ~1 s gives up, raises the error word next to the ticket and poisons its statistics with NaN, so a broken
-// co-residency assumption shows up as NaN outputs, never as a hung GPU.
+// global memory as TAGGED ENTRIES, without a barrier (round 3; rounds 1-2 used a ticket barrier + reload here): a row's
+// pair is one write-through 16-byte store {v0, tag, v1, tag}, tag = (launch sequence number, layer), and the team
+// that needs node index r polls the B entries of r with 16-byte sc1 loads until every tag is this launch's
+// (sm_poll_row).  The data is its own ready flag: no arrival counter, no acknowledgement wait on the producer's side,
+// one memory round trip on the consumer's.  B <= (CUs / 2) workgroups of 1024 threads are co-resident by construction
+// (one per CU; small_level_fused_ok also asks the occupancy calculator), so the wait cannot deadlock — and it is bounded
+// anyway: a team that polls longer than ~1 s gives up, raises the error words and poisons its statistics with NaN,
+// so a broken co-residency assumption shows up as NaN logits and DP_ERR_DEVICE on the next call, never as a hung GPU.
 //
-// Memory model (this is the part that is easy to get wrong on a multi-XCD part: each XCD has its own L2, and plain
-// stores / loads of different XCDs are not coherent inside one kernel): the exchanged partials are written with
-// agent-scope atomic stores (write-through to the device's coherence point) and read with agent-scope atomic loads
-// (served past the XCD-local L2); every thread waits for the acknowledgement of its stores (s_waitcnt vmcnt(0))
-// before the workgroup barrier that precedes the ticket.  The ticket and the spin are RELAXED agent-scope atomics
-// by default — the same ISA-level argument as the split-K combine (dp_gemm.hip, MEMORY-MODEL NOTE); building with
-// -DDP_BAR_ACQREL makes them a RELEASE fetch-add / ACQUIRE load pair (measured at the DD shape: no difference in
-// kernel time, 22.6 vs 23.0 us — the barrier's ~1.7 us is arrival skew plus one atomic round trip, and the
-// exchanged data never sit in a cache the fences would have to write back).
-// The tickets are zeroed in stream order by an earlier launch of the same sequence (never by a memset node).
-constexpr int SM_SPIN_LIMIT = 1 << 22;
-constexpr int SM_BMAX16 = 8;      // whole-level kernels take B <= 128 graphs (16 lanes x 8 partial pairs per node)
-#ifdef DP_BAR_ACQREL
-#define SM_BAR_RELEASE __ATOMIC_RELEASE
-#define SM_BAR_ACQUIRE __ATOMIC_ACQUIRE
-#else
-#define SM_BAR_RELEASE __ATOMIC_RELAXED
-#define SM_BAR_ACQUIRE __ATOMIC_RELAXED
-#endif
+// Memory model (each XCD has its own L2; plain stores / loads of different XCDs are not coherent inside one kernel):
+// entries are stored sc1 (write-through to memory) and polled sc1 (served past the XCD-local L2); each 8-byte half of
+// an entry carries its own tag, so an entry torn at 8 bytes is never mistaken for a whole one; the sequence number
+// lives in the workspace's first block (zero once), is read by every workgroup at kernel start and counted up by the
+// last workgroup to finish (sm_finish), so tags never repeat across launches or hipGraph replays.
 
-__device__ inline void sm_st_agent(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// The cross-graph BatchNorm exchange of the whole-level kernels, barrier-free (the scheme of dp_level0.hip "tagged
+// entries"): a row's pair travels as one write-through 16-byte entry {v0, tag, v1, tag}, tag = (launch sequence number,
+// layer); a 16-lane team polls the B entries of its node index until every tag is this launch's.  Returns false when the
+// wait gave up (and raises DP_DEVERR_BARRIER in the device's error word, which the next model-level entry reports:
+// diffpool_hip.h "Device-side failures"; bar[1] is the word the prediction head turns into NaN logits).
+__device__ inline bool sm_poll_row(ScBuf buf, unsigned off, int B, unsigned want, float (&v0)[SM_BMAX16],
+                                   float (&v1)[SM_BMAX16], int spin_limit, int* bar, int* dev_err) {
+    const int tl = threadIdx.x & 15;
+    int it = 0;
+    for (;;) {
+        bool ready = true;
+#pragma unroll
+        for (int u = 0; u < SM_BMAX16; ++u) {
+            v0[u] = 0.f;
+            v1[u] = 0.f;
+            if (16 * u < B) {                                              // (uniform)
+                const u32x4 q = sc_ld16(buf, off + 16u * (unsigned)min(tl + 16 * u, B - 1));
+                v0[u] = __uint_as_float(q[0]);
+                v1[u] = __uint_as_float(q[2]);
+                ready = ready && q[1] == want && q[3] == want;
+            }
+        }
+        if (__all(ready)) return true;
+        if (++it > spin_limit) {
+            __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dev_err_raise(dev_err, DP_DEVERR_BARRIER);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
 }
-__device__ inline float sm_ld_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// returns false when the wait gave up (and raises DP_DEVERR_BARRIER in the device's error word, which the next
-// model-level entry reports: diffpool_hip.h "Device-side failures").  `flag` is an LDS word.
-__device__ inline bool sm_grid_barrier(int* bar, int target, int* flag, int spin_limit, int* dev_err) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's exchange stores are acknowledged
+// the last workgroup to finish counts the sequence number up (every workgroup read it at kernel start)
+__device__ inline void sm_finish(int* bar, int* seq, unsigned mine, int B) {
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(bar, 1, SM_BAR_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        int it = 0, ok = 1;
-        while (__hip_atomic_load(bar, SM_BAR_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++it > spin_limit) {
-                ok = 0;
-                __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                dev_err_raise(dev_err, DP_DEVERR_BARRIER);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        *flag = ok;
+        const int old = __hip_atomic_fetch_add(bar + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == B - 1)
+            __hip_atomic_store(seq, (int)((mine + 1u) & 0x03ffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    return *flag != 0;
 }
 
 struct SmallLevelFwdArgs {
@@ -549,8 +551,9 @@ struct SmallLevelFwdArgs {
     float* Ze;                     // concat buffer [B, n, ldz]; layer l's slice starts at column coff[l]
     int ldz;
     int coff[DP_MAX_LAYERS];
-    float* part;                   // exchange: [L-1][B][n][2] (row mean, row M2) of relu(y)
-    int* bar;                      // bar[0] ticket (zero at launch), bar[1] error word
+    float* part;                   // exchange: [L-1][n][B] tagged 16-byte entries (row mean, row M2) of relu(y)
+    int* bar;                      // bar[1] error word, bar[2] finish ticket (zero at launch)
+    int* seq;                      // launch sequence number (tags of the exchange entries), counted up by the last workgroup
     int* dev_err;                  // the device's host-visible error word (or null)
     int spin_limit, target_bias;   // SM_SPIN_LIMIT, 0 (the test knob DP_TEST_BARRIER_FAIL: 64, 1)
     int B, n, add_self, bn;
@@ -560,9 +563,9 @@ struct SmallLevelFwdArgs {
 
 __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int bar_ok;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.n, L = a.L;
+    const unsigned seq = (unsigned)a.seq[0];               // launch sequence number: the tags of this launch's exchange entries
     float* A = lds;                        // [n][n]
     float* X = A + n * n;                  // [n][dmax]  current layer input
     float* P = X + n * a.dmax;             // [n][omax]
@@ -621,7 +624,8 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
         SM_STAMP(0, 11 + 6 * l);
         // l2-normalise rows -> y (kept in U), saved output, BN partials of relu(y)
         const bool stats = !last && a.bn;
-        float* part_l = a.part + (long)l * a.B * n * 2;
+        const ScBuf part_l = sc_buf(a.part + (long)l * a.B * n * 4, (size_t)a.B * n * 16);
+        const unsigned bn_tag = ((seq << 4) | (unsigned)(l + 1)) ^ (a.target_bias ? 0x40000000u : 0u);
         for (int r = team; r < n; r += NTEAMS) {
             const long row = (long)b * n + r;
             float ss = 0.f;
@@ -646,27 +650,19 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
                     m2 += v * v;
                 }
                 m2 = sm_team_sum(m2);
-                if (tl == 0) {
-                    sm_st_agent(part_l + row * 2, mean);
-                    sm_st_agent(part_l + row * 2 + 1, m2);
-                }
+                if (tl == 0) sc_st16(part_l, (unsigned)(((long)r * a.B + b) * 16), sc_tagged(mean, m2, (seq << 4) | (unsigned)(l + 1)));
             }
         }
         SM_STAMP(0, 12 + 6 * l);
         if (last) break;
         if (stats) {
             // every graph's partials of this layer, then the statistics per node index (Chan combine)
-            const bool ok = sm_grid_barrier(a.bar, (l + 1) * a.B + a.target_bias, &bar_ok, a.spin_limit, a.dev_err);
             SM_STAMP(0, 13 + 6 * l);
-            // one 16-lane team per node index: its B (mean, M2) pairs straight from the exchange buffer, one round trip
+            // one 16-lane team per node index: its B (mean, M2) entries, polled until all are this launch's
             for (int r = team; r < n; r += NTEAMS) {
                 float pm[SM_BMAX16], pq[SM_BMAX16];
-#pragma unroll
-                for (int u = 0; u < SM_BMAX16; ++u) {
-                    const int bb = min(tl + 16 * u, a.B - 1);
-                    pm[u] = sm_ld_agent(part_l + ((long)bb * n + r) * 2);
-                    pq[u] = sm_ld_agent(part_l + ((long)bb * n + r) * 2 + 1);
-                }
+                const bool ok = sm_poll_row(part_l, (unsigned)((long)r * a.B * 16), a.B, bn_tag, pm, pq, a.spin_limit, a.bar,
+                                            a.dev_err);
                 float sm = 0.f;
 #pragma unroll
                 for (int u = 0; u < SM_BMAX16; ++u) sm += (tl + 16 * u < a.B) ? pm[u] : 0.f;
@@ -708,6 +704,7 @@ __global__ __launch_bounds__(1024) void k_small_level_fwd(SmallLevelFwdArgs a) {
         wo += din * dout;
         bo += dout;
     }
+    sm_finish(a.bar, a.seq, seq, a.B);
 }
 
 struct SmallLevelBwdArgs {
@@ -732,6 +729,7 @@ struct SmallLevelBwdArgs {
     long slab_stride;
     float* part;                       // exchange: [L-1][B][n][2] (sum dx, sum dx * xhat)
     int* bar;
+    int* seq;
     int* dev_err;
     int spin_limit, target_bias;
     int B, n, add_self, bn;
@@ -742,9 +740,9 @@ struct SmallLevelBwdArgs {
 
 __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int bar_ok;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.n, L = a.L, D = a.D, d0 = a.dims[0];
+    const unsigned seq = (unsigned)a.seq[0];
     float* A = lds;                        // [n][n]
     float* DA = A + n * n;                 // [n][n] running dA (only when wanted)
     float* X0 = DA + (a.dadj ? n * n : 0); // [n][d0]
@@ -795,7 +793,6 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
     __syncthreads();                       // (drains the LDS-DMA burst: vmcnt)
 
     int wo_end = a.wtot;
-    int nbar = 0;
     for (int l = L - 1; l >= 0; --l) {
         const int din = a.dims[l], dout = a.dims[l + 1];
         const bool last = l == L - 1;
@@ -811,7 +808,8 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
         for (int i = tid; i < 16 * dout; i += NT) DBW[i] = 0.f;
         if (has_bn) {
             // BN backward needs, per node index, the sums over ALL graphs of (dx, dx * xhat)
-            float* part_l = a.part + (long)l * a.B * n * 2;
+            const ScBuf part_l = sc_buf(a.part + (long)l * a.B * n * 4, (size_t)a.B * n * 16);
+            const unsigned bn_tag = (seq << 4) | (unsigned)(l + 1);
             const float* xh = ZE + a.coff[l];
             for (int r = team; r < n; r += NTEAMS) {
                 float s0 = 0.f, s1 = 0.f;
@@ -822,21 +820,12 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
                 }
                 s0 = sm_team_sum(s0);
                 s1 = sm_team_sum(s1);
-                if (tl == 0) {
-                    sm_st_agent(part_l + ((long)b * n + r) * 2, s0);
-                    sm_st_agent(part_l + ((long)b * n + r) * 2 + 1, s1);
-                }
+                if (tl == 0) sc_st16(part_l, (unsigned)(((long)r * a.B + b) * 16), sc_tagged(s0, s1, bn_tag));
             }
-            ++nbar;
-            const bool ok = sm_grid_barrier(a.bar, nbar * a.B + a.target_bias, &bar_ok, a.spin_limit, a.dev_err);
             for (int r = team; r < n; r += NTEAMS) {
                 float p0[SM_BMAX16], p1[SM_BMAX16];
-#pragma unroll
-                for (int u = 0; u < SM_BMAX16; ++u) {
-                    const int bb = min(tl + 16 * u, a.B - 1);
-                    p0[u] = sm_ld_agent(part_l + ((long)bb * n + r) * 2);
-                    p1[u] = sm_ld_agent(part_l + ((long)bb * n + r) * 2 + 1);
-                }
+                const bool ok = sm_poll_row(part_l, (unsigned)((long)r * a.B * 16), a.B,
+                                            bn_tag ^ (a.target_bias ? 0x40000000u : 0u), p0, p1, a.spin_limit, a.bar, a.dev_err);
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int u = 0; u < SM_BMAX16; ++u) {
@@ -932,6 +921,7 @@ __global__ __launch_bounds__(1024) void k_small_level_bwd(SmallLevelBwdArgs a) {
     }
     if (a.dadj)
         for (int i = tid; i < n * n; i += NT) a.dadj[(long)b * n * n + i] = DA[i];
+    sm_finish(a.bar, a.seq, seq, a.B);
 }
 
 size_t small_lds_floats_fwd(int B, int n, int din, int dout) {
@@ -1057,7 +1047,7 @@ bool small_level_fused_ok(int B, int n, const int* dims, int L, bool dadj) {
     const int cus = device_cus();
     return cus > 0 && B <= cus / 2 && B <= 16 * SM_BMAX16 && level_kernels_admitted();
 }
-size_t small_level_part_floats(int B, int n, int L) { return (size_t)(L > 1 ? L - 1 : 1) * B * n * 2; }
+size_t small_level_part_floats(int B, int n, int L) { return (size_t)(L > 1 ? L - 1 : 1) * B * n * 4; }
 
 void small_level_fwd(Seq& q, const SmallLevelIO& io, int B, int n, const int* dims, int L, int add_self, int bn) {
     if (!q.ok()) return;
@@ -1066,7 +1056,7 @@ void small_level_fwd(Seq& q, const SmallLevelIO& io, int B, int n, const int* di
     if (!q.ok()) return;
     SmallLevelFwdArgs a{};
     a.adj = io.adj; a.x0 = io.x0; a.ldx0 = io.ldx0; a.params = io.params; a.L = L;
-    a.Ze = io.Ze; a.ldz = io.ldz; a.part = io.part; a.bar = io.bar;
+    a.Ze = io.Ze; a.ldz = io.ldz; a.part = io.part; a.bar = io.bar; a.seq = q.seq_word;
     a.B = B; a.n = n; a.add_self = add_self; a.bn = bn;
     for (int l = 0; l <= L; ++l) a.dims[l] = dims[l];
     for (int l = 0; l < L; ++l) {
@@ -1095,7 +1085,7 @@ void small_level_bwd(Seq& q, const SmallLevelIO& io, const float* dZe, float* dX
     if (!q.ok()) return;
     SmallLevelBwdArgs a{};
     a.adj = io.adj; a.x0 = io.x0; a.ldx0 = io.ldx0; a.params = io.params; a.L = L;
-    a.Ze = io.Ze; a.ldz = io.ldz; a.part = io.part; a.bar = io.bar;
+    a.Ze = io.Ze; a.ldz = io.ldz; a.part = io.part; a.bar = io.bar; a.seq = q.seq_word;
     a.dZe = dZe; a.dX0 = dX0; a.dadj = dadj; a.slabs = slabs; a.slab_stride = slab_stride;
     a.B = B; a.n = n; a.add_self = add_self; a.bn = bn;
     for (int l = 0; l <= L; ++l) a.dims[l] = dims[l];
