@@ -494,6 +494,9 @@ __global__ __launch_bounds__(1024) void k_small_gcn_bwd(SmallBwdArgs a) {
 // an entry carries its own tag, so an entry torn at 8 bytes is never mistaken for a whole one; the sequence number
 // lives in the workspace's first block (zero once), is read by every workgroup at kernel start and counted up by the
 // last workgroup to finish (sm_finish), so tags never repeat across launches or hipGraph replays.
+// The finish ticket (bar[2]) is zeroed in stream order by an earlier launch of the same sequence (never by a memset node).
+constexpr int SM_SPIN_LIMIT = 1 << 22;
+constexpr int SM_BMAX16 = 8;      // whole-level kernels take B <= 128 graphs (16 lanes x 8 entries per node)
 
 // The cross-graph BatchNorm exchange of the whole-level kernels, barrier-free (the scheme of dp_level0.hip "tagged
 // entries"): a row's pair travels as one write-through 16-byte entry {v0, tag, v1, tag}, tag = (launch sequence number,
