@@ -1751,8 +1751,8 @@ size_t level0_mpart_floats(const Level0Fwd& f) {
 bool level0_persistent_ok(const Level0Fwd& f) {
     if (knobs().no_l0_persist) return false;
     if (f.G < 1 || f.G > 2 || f.L < 1 || f.L > DP_MAX_LAYERS) return false;
-    if (f.N < 128 || (f.N & 3) || f.B < 1 || f.B > 16 * L0_BPAIRS) return false;
-    if (!adj_pack_supported(f.N, 1)) return false;
+    if (knobs().no_pack) return false;                       // (the fp32-everywhere ablation)
+    if (f.N < 64 || (f.N & 3) || f.B < 1 || f.B > 16 * L0_BPAIRS) return false;
     for (int l = 0; l < f.L; ++l) {
         int ct = 0;
         size_t wfl = 0;

@@ -120,11 +120,15 @@ int readout_width(const dp_encoder_cfg& c, const LevelInfo& li) {
     return (c.flags & DP_F_LAST_ONLY) ? li.e->dims[li.L] : li.D;
 }
 
+bool level0_persistent(const dp_encoder_cfg& c);
+
 SaveLayout layout_save(const dp_encoder_cfg& c, void* base) {
     SaveLayout s{};
     Bump b{(char*)base, 0};
     const size_t B = c.B;
-    if (adj_pack_supported(c.N, 1)) {
+    // the bf16 copies of A / A^T: for the packed aggregation kernels (N >= 128) and for the persistent level-0 pair
+    // (which keeps them for its backward at any N it takes)
+    if (adj_pack_supported(c.N, 1) || level0_persistent(c)) {
         s.pk_ld = adj_pack_ld(c.N);
         s.pkA = b.take<unsigned short>(B * c.N * s.pk_ld);
         s.pkAt = b.take<unsigned short>(B * c.N * s.pk_ld);
@@ -918,7 +922,7 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
         // the level-0 adjacency arrives as the packed bf16 pair (dp_build_batch_packed) instead of fp32: only the
         // persistent level-0 kernels multiply straight from it (every other plan wants the fp32 rows somewhere)
         if (!level0_persistent(c) || !level0_bwd_persistent(c)) {
-            set_error("the packed-adjacency entry needs the persistent level-0 plan (N >= 128, N %% 4 == 0, B * ceil(N / RB) "
+            set_error("the packed-adjacency entry needs the persistent level-0 plan (N >= 64, N %% 4 == 0, B * ceil(N / RB) "
                       "<= CUs, no sync-BN); pass the fp32 adjacency to dp_encoder_forward for this configuration");
             return q.err = DP_ERR_UNSUPPORTED;
         }

@@ -349,7 +349,7 @@ int dp_encoder_backward(const dp_encoder_cfg* cfg, const float* params, const fl
  * [B, N, dp_adj_pack_ld(N)] of A (adj_pk) and of A^T (adj_pkt; the same buffer for a symmetric adjacency), as written
  * by dp_build_batch_packed or dp_adj_pack: no fp32 [B,N,N] batch is written, read or converted (the
  * end-to-end training step).  The bf16 values ARE the adjacency (nothing to round).  Only configurations that take the
- * persistent level-0 plan accept it (N >= 128, N % 4 == 0, B * ceil(N / RB) <= CUs, no sync-BN, no add_self):
+ * persistent level-0 plan accept it (N >= 64, N % 4 == 0, B * ceil(N / RB) <= CUs, no sync-BN, no add_self):
  * DP_ERR_UNSUPPORTED otherwise — the fp32 entries above serve every configuration and train.py.  The link-prediction
  * loss (dp_loss_forward with linkpred) reads the fp32 adjacency and has no packed form. */
 int dp_encoder_forward_packed(const dp_encoder_cfg* cfg, const float* params, const float* x, const void* adj_pk,

@@ -66,11 +66,11 @@ def test_packed_builder_drives_the_encoder_bit_identically_to_the_fp32_builder(B
 
 
 def test_packed_entry_refuses_a_configuration_outside_the_persistent_plan():
-    """N = 100 < 128 runs the small-level kernels, which read the fp32 adjacency: DP_ERR_UNSUPPORTED, not a wrong result."""
-    graphs = _graphs(6, 20, 100, 3, 0.1, seed=3)
+    """N = 48 < 64 runs the small-level kernels, which read the fp32 adjacency: DP_ERR_UNSUPPORTED, not a wrong result."""
+    graphs = _graphs(6, 10, 48, 3, 0.1, seed=3)
     ds = EdgeListDataset.from_tu_graphs(graphs)
-    batch = DeviceBatchBuilder(ds, 100, 3, "cuda").build(range(6), packed=True)
-    model = _model(100, 3, 8, 0.1)
+    batch = DeviceBatchBuilder(ds, 48, 3, "cuda").build(range(6), packed=True)
+    model = _model(48, 3, 8, 0.25)
     with pytest.raises(RuntimeError, match="packed-adjacency entry needs the persistent"):
         model(batch["feats"], batch["adj"], batch["num_nodes_device"], assign_x=batch["feats"])
 
