@@ -880,6 +880,21 @@ bool level0_persistent(const dp_encoder_cfg& c) {
     return level0_persistent_ok(level0_desc(c));
 }
 
+// The tagged-entry exchange regions (BatchNorm partials of the persistent level-0 kernels, forward and backward, and of
+// the pooled-level kernels).  Their readers recognise an entry by its tag, so NOTHING else may ever be written there:
+// they sit right behind the barrier block, at the same offsets in the forward and the backward walk, and are never
+// handed out as scratch — they only ever hold zeros (the workspace's one-time fill) or entries of earlier launches.
+struct ExchangeRegions {
+    float *l0_fwd, *l0_bwd, *lvl;
+};
+ExchangeRegions alloc_exchange(Seq& q, const dp_encoder_cfg& c) {
+    ExchangeRegions x{};
+    x.l0_fwd = q.alloc<float>(level0_persistent(c) ? level0_part_floats(level0_desc(c)) : 4);
+    x.l0_bwd = q.alloc<float>(level0_bwd_persistent(c) ? level0_bwd_part_floats(level0_bwd_desc(c)) : 4);
+    x.lvl = q.alloc<float>(level_part_floats(c));
+    return x;
+}
+
 // shared allocation walk for the forward (also used for sizing)
 Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
     size_t maxPU = 0, maxPart = 0, maxLog = 0;
@@ -896,14 +911,12 @@ Scratch fwd_scratch(Seq& q, const dp_encoder_cfg& c) {
     s.part = q.alloc<float>(maxPart);
     s.part_b = q.alloc<float>(maxPart);
     s.logits = q.alloc<float>(maxLog > 0 ? maxLog : 1);
-    s.lvl_part = q.alloc<float>(level_part_floats(c));
     s.part_all = bn_sync(c) ? q.alloc<float>(maxPart * bn_world(c)) : nullptr;
     s.vs = q.alloc<unsigned short>(vs_elems(c));
     if (level0_persistent(c)) {
         const Level0Fwd f = level0_desc(c);
         s.xpart = q.alloc<float>(level0_xpart_floats(f));
         s.mpart = q.alloc<float>(level0_mpart_floats(f));
-        s.l0_part = q.alloc<float>(level0_part_floats(f));
         s.l0_vs = q.alloc<unsigned short>(level0_vs_elems(f));
     }
     const size_t dsf = dropout_scratch_floats(c);
@@ -933,8 +946,11 @@ int encoder_forward(Seq& q, const dp_encoder_cfg& c, const float* params, const 
     // is first used (diffpool_hip.h), self-cleaning afterwards (dp_level0.hip)
     int* l0_bar = q.alloc<int>(level0_bar_ints(c.B));
     q.seq_word = level0_seq_word(l0_bar);
+    const ExchangeRegions xr = alloc_exchange(q, c);
     const BwdZero bz = alloc_bwd_zero(q, c);      // same offsets as in encoder_backward: next block of the workspace
     Scratch sc = fwd_scratch(q, c);
+    sc.lvl_part = xr.lvl;
+    sc.l0_part = xr.l0_fwd;
     if (q.err) return q.err;
     const int B = c.B, P = c.num_pooling;
     const int ldfeat = c.pred_dims[0];
@@ -1114,6 +1130,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     // (the forward's barrier block, then) zero-initialised gradient accumulators + slabs: ONE block (alloc_bwd_zero)
     int* l0_bar = q.alloc<int>(level0_bar_ints(c.B));
     q.seq_word = level0_seq_word(l0_bar);
+    const ExchangeRegions xr = alloc_exchange(q, c);
     const BwdZero bz = alloc_bwd_zero(q, c);
     const bool l0_persist = level0_bwd_persistent(c);
     unsigned short* l0_vs = nullptr;
@@ -1121,7 +1138,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     if (l0_persist) {
         const Level0Bwd f0 = level0_bwd_desc(c);
         l0_vs = q.alloc<unsigned short>(level0_bwd_vs_elems(f0));
-        l0_part = q.alloc<float>(level0_bwd_part_floats(f0));
+        l0_part = xr.l0_bwd;
         l0_gpart = q.alloc<float>(level0_bwd_gpart_floats(f0));
     }
     LevelGrad gr[DP_MAX_LEVELS + 1]{};
@@ -1143,7 +1160,7 @@ int encoder_backward(Seq& q, const dp_encoder_cfg& c, const float* params, const
     float* Gj = q.alloc<float>(maxPU);
     float* part = q.alloc<float>(maxPart);
     float* part_b = q.alloc<float>(maxPart);
-    float* lvl_part = q.alloc<float>(level_part_floats(c));
+    float* lvl_part = xr.lvl;
     float* part_all = bn_sync(c) ? q.alloc<float>(maxPart * bn_world(c)) : nullptr;
     unsigned short* vs = q.alloc<unsigned short>(vs_elems(c));
     float* dS = q.alloc<float>(maxSK ? maxSK : 1);
