@@ -69,6 +69,8 @@ def _run_case(B, N, F_, H, Cc, ratio, p, linkpred, *, seed=1, n_min=None, sizes=
 
 
 @pytest.mark.parametrize("B,N,F_,H,Cc,ratio,p,linkpred,tag", [
+    (20, 100, 3, 20, 6, 0.1, 0.10, True, "the ENZYMES shape (N < 128: no packed aggregation kernels, persistent pair only)"),
+    (4, 64, 5, 8, 3, 0.25, 0.15, False, "smallest level the pair takes"),
     (6, 160, 8, 12, 3, 0.1, 0.05, False, "16-row blocks"),
     (5, 132, 8, 12, 3, 0.1, 0.05, True, "16-row blocks, last block of 4 rows, link loss"),
     (20, 256, 16, 20, 2, 0.2, 0.03, False, "32-row blocks"),
