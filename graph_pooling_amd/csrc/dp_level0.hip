@@ -447,7 +447,10 @@ __device__ __forceinline__ void l0_aggregate_pass(const Args& a, const unsigned 
 template <int MI, typename Args>
 __device__ __forceinline__ void l0_aggregate(const Args& a, const unsigned short* Alds, bool exact, const float* Ag, long rs,
                                              long ks, int nrows, const unsigned short* vsb, int CTt, float* red, int ctp, int rot) {
-    const int cth = (CTt + 1) >> 1;
+    // tiles of THIS wave's column half (wave-uniform): the narrower half of an odd tile count takes the narrower
+    // instantiation instead of multiplying a clamped duplicate of the last tile
+    const int cta_ = (CTt + 1) >> 1;
+    const int cth = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >> 2) ? CTt - cta_ : cta_;
     if (cth <= 1) l0_aggregate_pass<MI, 1>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp, rot);
     else if (cth == 2) l0_aggregate_pass<MI, 2>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp, rot);
     else l0_aggregate_pass<MI, 3>(a, Alds, exact, Ag, rs, ks, nrows, vsb, CTt, red, ctp, rot);
