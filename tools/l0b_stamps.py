@@ -22,7 +22,7 @@ for i in range(3):
     names.update({o: f"layer {2 - i}: rownorm bwd + sync", o + 1: f"layer {2 - i}: bias sums, split, x_in / W staged",
                   o + 2: f"layer {2 - i}: graph barrier (+ A^T rows)", o + 3: f"layer {2 - i}: A^T dU aggregate + sync",
                   o + 4: f"layer {2 - i}: reduce to G + sync", o + 5: f"layer {2 - i}: dW, dx_in + sync",
-                  o + 6: f"layer {2 - i}: dW stored, BN partials", o + 7: f"layer {2 - i}: column barrier / sync"})
+                  o + 6: f"layer {2 - i}: dW stored, BN partials", o + 7: f"layer {2 - i}: exchange (polled at the next phase) / sync"})
 names.update({40: "graph barrier (gradients)", 41: "combine + sync"})
 sub = {}
 for i in range(3):
