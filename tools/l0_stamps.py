@@ -22,8 +22,8 @@ names = {0: "entry", 1: "side zero", 2: "A rows -> LDS + pkA", 3: "x, W0 staged 
          6: "P0 split written", 7: "graph barrier 0"}
 for l in range(3):
     o = 8 + 8 * l
-    names.update({o: f"L{l} aggregate", o + 1: f"L{l} sync", o + 2: f"L{l} tail", o + 3: f"L{l} column barrier",
-                  o + 4: f"L{l} BN apply + sync", o + 5: f"L{l} transform + sync", o + 6: f"L{l} split written",
+    names.update({o: f"L{l} aggregate", o + 1: f"L{l} sync", o + 2: f"L{l} tail", o + 3: f"L{l} (no barrier: polled below)",
+                  o + 4: f"L{l} BN entries polled + apply + sync", o + 5: f"L{l} transform + sync", o + 6: f"L{l} split written",
                   o + 7: f"L{l} graph barrier"})
 names.update({40: "Wp staged + sync", 41: "logits mma + sync", 42: "softmax + sync", 43: "S split written",
               44: "graph barrier S", 45: "A^T rows in LDS + sync", 46: "A^T S aggregate", 47: "sync", 48: "T reduce + sync",
