@@ -1305,6 +1305,31 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
         const int CTt = (ct + 15) / 16, ctp = ct | 1;
         const int pass = 1 + (L - 1 - l);
         float* DU = SCR;                                   // [RB][ct]  (reduce-slot area: free until the pass)
+        // The saved forward values of ALL my row items (y, xhat, 1 / norm, rstd) are asked for first, in one go: taken item
+        // by item inside the loop below, each item paid its own memory round trip (3 k cycles per item and layer)
+        float rw_y[ITEMS][L0_NK], rw_x[ITEMS][L0_NK], rw_inv[ITEMS], rw_rstd[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int it = team + j * L0_TEAMS;
+            const int r = min(G == 2 ? it >> 1 : it, RB - 1), g = G == 2 ? (it & 1) : 0;
+            const int node = min(r0 + r, N - 1);
+            const long row = (long)b * N + node;
+            const int wg = g ? w1 : w0, c0gg = g ? w0 : 0;
+            const float* yp = last ? f.Z[g] + row * f.ldz[g] + f.coff[g][l] : f.Y[l] + row * ct + c0gg;
+            const float* xp = f.Z[g] + row * f.ldz[g] + f.coff[g][l];
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                rw_y[j][k] = 0.f;
+                rw_x[j][k] = 0.f;
+                if (16 * k < wmax) {
+                    const int c = min(tl + 16 * k, wg - 1);
+                    rw_y[j][k] = yp[c];
+                    if (has_bn) rw_x[j][k] = xp[c];
+                }
+            }
+            rw_inv[j] = f.invn[l][row * G + g];
+            rw_rstd[j] = has_bn ? f.stats[l][((long)node * G + g) * 2 + 1] : 1.f;
+        }
         // ---- BatchNorm-backward means of my node indices: every graph's (sum dx, sum dx xhat) partials -> (m0, m1) in LDS
         float* M01 = EXT;                                  // [RB * G][2]
         if (has_bn) {
@@ -1349,17 +1374,10 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
             const int node = min(r0 + r, N - 1);
             const long row = (long)b * N + node;
             const int wg = g ? w1 : w0, c0gg = g ? w0 : 0;
-            const float* yp = last ? f.Z[g] + row * f.ldz[g] + f.coff[g][l] : f.Y[l] + row * ct + c0gg;
-            const float* xp = f.Z[g] + row * f.ldz[g] + f.coff[g][l];
-            float yv[L0_NK], xh[L0_NK];
-#pragma unroll
-            for (int k = 0; k < L0_NK; ++k) {
-                const int c = min(tl + 16 * k, wg - 1);
-                yv[k] = yp[c];
-                xh[k] = xp[c];
-            }
-            const float inv = f.invn[l][row * G + g];
-            const float rstd = has_bn ? f.stats[l][((long)node * G + g) * 2 + 1] : 1.f;
+            const float (&yv)[L0_NK] = rw_y[j];
+            const float (&xh)[L0_NK] = rw_x[j];
+            const float inv = rw_inv[j];
+            const float rstd = rw_rstd[j];
             const float m0 = has_bn ? M01[min(it, RB * G - 1) * 2] : 0.f;
             const float m1 = has_bn ? M01[min(it, RB * G - 1) * 2 + 1] : 0.f;
             const float* dzr = (g ? DZ1 : DZ0) + r * f.ldz[g] + f.coff[g][l];
