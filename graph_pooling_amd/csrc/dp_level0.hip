@@ -1236,14 +1236,28 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
         lds_barrier();
         L0B_STAMP(4);
         float* DLOG = DS;                                  // in place, row by row
-        for (int r = team; r < RB; r += L0_TEAMS) {
-            const long row = (long)b * N + min(r0 + r, N - 1);
-            float sv[L0_NK], dv[L0_NK];
+        // S (and the link loss's d_assign) of all my rows first: one memory round trip, not one per row round
+        constexpr int RROUNDS = (RB + L0_TEAMS - 1) / L0_TEAMS;
+        float svq[RROUNDS][L0_NK], dvq[RROUNDS][L0_NK];
+#pragma unroll
+        for (int q = 0; q < RROUNDS; ++q) {
+            const long row = (long)b * N + min(r0 + min(team + q * L0_TEAMS, RB - 1), N - 1);
 #pragma unroll
             for (int k = 0; k < L0_NK; ++k) {
                 const int c = min(tl + 16 * k, K - 1);
-                sv[k] = f.S[row * K + c];
-                dv[k] = f.d_assign ? f.d_assign[row * K + c] : 0.f;
+                svq[q][k] = f.S[row * K + c];
+                dvq[q][k] = f.d_assign ? f.d_assign[row * K + c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RROUNDS; ++q) {
+            const int r = team + q * L0_TEAMS;
+            if (r >= RB) break;
+            float sv[L0_NK], dv[L0_NK];
+#pragma unroll
+            for (int k = 0; k < L0_NK; ++k) {
+                sv[k] = svq[q][k];
+                dv[k] = dvq[q][k];
             }
             float dot = 0.f;
 #pragma unroll
@@ -1275,10 +1289,13 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
             l0_mma<true, false>(DLOG, K, ZAL, Da, K, Da, RB, [&](int i, int j, float v) { STG[i * Da + j] = v; });
             l0_mma<false, false>(DLOG, K, WP, Da, RB, Da, K, [&](int r, int j, float v) { DZ1[r * Da + j] = v; }, 4);
             float* SB = STG + ((K * Da + 3) & ~3);
-            for (int c = tid; c < K; c += L0_NT) {
+            // dbp: column sums of dlog over my rows — one 16-lane team per column, RB / 16 rows per lane, fixed tree order
+            for (int c = team; c < K; c += L0_TEAMS) {
                 float t = 0.f;
-                for (int r = 0; r < RB; ++r) t += DLOG[r * K + c];
-                SB[c] = t;
+#pragma unroll
+                for (int rr = 0; rr < RB / 16; ++rr) t += DLOG[(tl * (RB / 16) + rr) * K + c];
+                t = row16_sum(t);
+                if (tl == 0) SB[c] = t;
             }
             lds_barrier();
             l0_put_compact(gp, a.cwp, STG, K * Da);
