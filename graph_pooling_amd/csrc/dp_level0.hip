@@ -1474,6 +1474,10 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
 #pragma unroll
                         for (int k = 0; k < L0_NK; ++k) xv[j][k] = src[min(tl + 16 * k, dg - 1)];
                     }
+                    // the weights are asked for behind the rows and land with them (one round trip for both)
+                    const L0Copy jw[2] = {{W0, f.params + f.st[0].w_off[l], d0 * w0, 0},
+                                          {W1, G == 2 ? f.params + f.st[1].w_off[l] : f.params, G == 2 ? d1 * w1 : 0, 0}};
+                    l0_copy_many<2, 2>(jw);
 #pragma unroll
                     for (int j = 0; j < ITEMS; ++j) {
                         const int it = team + j * L0_TEAMS;
@@ -1485,9 +1489,6 @@ __global__ __launch_bounds__(L0_NT) void k_level0_bwd(L0BArgs a) {
                             if (tl + 16 * k < dg && it < RB * G) dst[tl + 16 * k] = r < nrows ? xv[j][k] : 0.f;
                     }
                 }
-                const L0Copy jw[2] = {{W0, f.params + f.st[0].w_off[l], d0 * w0, 0},
-                                      {W1, G == 2 ? f.params + f.st[1].w_off[l] : f.params, G == 2 ? d1 * w1 : 0, 0}};
-                l0_copy_many<2, 2>(jw);
             } else {
                 const L0Copy jx[1] = {{XIN0, f.x0[0] + rowo * d0, nrows * d0, RB * d0}};
                 l0_copy_many<1, 4>(jx);
