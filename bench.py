@@ -248,6 +248,9 @@ def level0_probe(w, model, fwd_bwd, steps=30):
             "hbm", f"{name}: persistent level-0 {'backward' if which else 'forward'}, one workgroup per (graph, row "
                    f"block), bf16 adjacency rows resident in LDS", alg, us, _profiled(name, shape), HBM_PEAK_GBS, "GB/s",
             algorithmic_bytes=alg, adjacency_passes_stood_for=passes, launches_timed=out[which][1],
+            fp32_equiv=(lambda bts, ns: {"bytes": bts, "GB/s": round(bts / ns, 1), "frac": round(bts / ns / HBM_PEAK_GBS, 4),
+                                         "note": "the same passes at the reference's 4-byte adjacency element"})(
+                passes * B * N * N * 4 + act, (_profiled(name, shape).get("rocprof_avg_ns") or us * 1e3)),
             note="latency-bound by construction at B=20: the kernel reads the adjacency from HBM once instead of "
                  "once per pass, so HBM traffic is a fraction of the algorithmic bytes")
     return res
