@@ -33,6 +33,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_G
 # the persistent level-0 kernels, in the step itself (eager launches: counters per dispatch)
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_step_fetch -o f -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-graph > $O/pmc_step_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_step_write -o w -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-graph > $O/pmc_step_write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_step_mfma -o m -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-graph > $O/pmc_step_mfma.log 2>&1
 echo pmc done
 cd $R
 python3 tools/pmc_summary.py $(ls $O/pmc_fetch/*counter_collection.csv | head -1) k_aggregate > $O/pmc_dd_probe_summary.csv
@@ -42,6 +43,7 @@ python3 tools/pmc_summary.py $(ls $O/pmc_er_write/*counter_collection.csv | head
 python3 tools/pmc_summary.py $(ls $O/pmc_er_mfma/*counter_collection.csv | head -1) k_aggregate | tail -n +2 >> $O/pmc_er_probe_summary.csv
 python3 tools/pmc_summary.py $(ls $O/pmc_step_fetch/*counter_collection.csv | head -1) k_level0 > $O/pmc_dd_step_summary.csv
 python3 tools/pmc_summary.py $(ls $O/pmc_step_write/*counter_collection.csv | head -1) k_level0 | tail -n +2 >> $O/pmc_dd_step_summary.csv
+python3 tools/pmc_summary.py $(ls $O/pmc_step_mfma/*counter_collection.csv | head -1) k_level0 | tail -n +2 >> $O/pmc_dd_step_summary.csv
 python3 tools/step_trace.py $(ls $O/prof_dd/*kernel_trace.csv | head -1) > $O/step_trace_dd.txt
 rm -rf $O/pmc_*/*kernel_trace.csv $O/pmc_*/*counter_collection.csv $O/prof_*/*kernel_trace.csv
 cat $O/pmc_dd_probe_summary.csv $O/pmc_er_probe_summary.csv; tail -1 $O/bench_dd.json | cut -c1-400
