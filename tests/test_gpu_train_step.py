@@ -142,3 +142,15 @@ def test_captured_training_step_follows_the_eager_training_loop():
     assert len(set(losses_c)) == 5                   # five different batches were really trained on
     for (k, pe), (_, pc) in zip(eager.named_parameters(), cap.named_parameters()):
         np.testing.assert_allclose(pc.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+def test_packed_adjacency_from_dense_refuses_values_bf16_cannot_hold():
+    """PackedAdjacency.from_dense is dp_adj_pack + its exactness flag: a weighted adjacency must use the fp32 entry."""
+    from graph_pooling_amd.encoders import PackedAdjacency
+    adj = torch.zeros(2, 128, 128, device="cuda")
+    adj[0, 3, 5] = adj[0, 5, 3] = 1.0
+    pa = PackedAdjacency.from_dense(adj)
+    assert pa.pk.shape == (2, 128, 128) and int(pa.pk[0, 3, 5]) == 0x3F80 and int(pa.pkt[0, 5, 3]) == 0x3F80
+    adj[1, 7, 9] = 0.1                                   # not representable in 8 mantissa bits
+    with pytest.raises(ValueError, match="bf16 cannot hold"):
+        PackedAdjacency.from_dense(adj)

@@ -130,3 +130,24 @@ def test_supervised_graphsage_head_on_a_stub_encoder():
         head([0, 4, 7, 10])
     with pytest.raises(ValueError):
         SupervisedGraphSage(0, Enc())
+
+
+def test_captured_train_step_checks_its_arguments_before_touching_the_gpu():
+    """train_step.CapturedTrainStep needs the device-counted optimizer and has no link loss (the packed adjacency has no
+    fp32 form for it): both are refused up front, on any host."""
+    import numpy as np
+    from graph_pooling_amd.batch_builder import DeviceBatchBuilder, EdgeListDataset
+    from graph_pooling_amd.encoders import SoftPoolingGcnEncoder
+    from graph_pooling_amd.optim import FusedClipAdam
+    from graph_pooling_amd.train_step import CapturedTrainStep
+    from graph_pooling_amd.tu_dataset import TUGraph
+    a = np.zeros((3, 3), dtype=np.float32)
+    a[0, 1] = a[1, 0] = 1
+    ds = EdgeListDataset.from_tu_graphs([TUGraph(a, np.zeros(3, dtype=np.int64), 0)] * 4)
+    builder = DeviceBatchBuilder(ds, 64, 2, "cpu")
+    model = SoftPoolingGcnEncoder(64, 2, 4, 4, 2, 3, 4, assign_ratio=0.25, linkpred=False)
+    with pytest.raises(ValueError, match="device_step_counter"):
+        CapturedTrainStep(model, FusedClipAdam(model), builder, 2)
+    link = SoftPoolingGcnEncoder(64, 2, 4, 4, 2, 3, 4, assign_ratio=0.25, linkpred=True)
+    with pytest.raises(ValueError, match="link-prediction"):
+        CapturedTrainStep(link, FusedClipAdam(link, device_step_counter=True), builder, 2)
